@@ -1,0 +1,261 @@
+/*
+ * revo_hip.h -- C ABI of the MI355X-native REVO hot path (librevo_hip.so).
+ *
+ * The reference (fabianschenk/REVO) has no FFI/plugin layer: its hot path is a
+ * set of C++ classes (ImgPyramidRGBD, TrackerNew, Optimizer) linked into one
+ * executable.  This header is the drop-in boundary for that method surface:
+ * plain pointers and sizes, POD structs, no Eigen / cv / torch types.  Every
+ * entry point cites the reference interface it replaces (paths relative to the
+ * reference tree).  The header-only C++ adapters in revo_amd/cpp/ re-create the
+ * reference class names on top of it.
+ *
+ * Conventions
+ *   - return value 0 = REVO_OK, negative = error; revo_last_error() gives text
+ *     (thread-local).  The reference has no error codes (log + exit(0) /
+ *     assert / Sophus abort()); the adapters translate.
+ *   - R is a 3x3 rotation in COLUMN-major order (Eigen::Matrix3f storage),
+ *     T a 3-vector; together they map CURRENT-frame points into the
+ *     KEYFRAME (tracker.cpp:286-288, optimizer.cpp:93).
+ *   - 4x4 poses are column-major (Eigen::Matrix4f storage).
+ *   - images are row-major with a byte stride (cv::Mat layout).
+ *   - level 0 = full resolution (PYR_MAX_LVL), level PYR_MIN_LVL = coarsest.
+ *   - every call does hipSetDevice(ctx device) itself; a pyramid may be created
+ *     on one host thread and consumed on another (iowrapperRGBD.cpp:279 vs
+ *     system.cpp:188), but one handle must not be used concurrently.
+ */
+#ifndef REVO_HIP_H
+#define REVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REVO_MAX_LEVELS 6 /* optimizer.h:37 PYRAMID_LEVELS */
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+  REVO_OK = 0,
+  REVO_ERR_INVALID_ARG = -1,
+  REVO_ERR_HIP = -2,          /* a HIP runtime call failed / no device        */
+  REVO_ERR_NOT_KEYFRAME = -3, /* imgpyramidrgbd.h:113-116 "optimizationStructure not built" */
+  REVO_ERR_NOT_ORTHOGONAL = -4, /* Sophus SO3(R) ENSURE, so3.hpp:419-424       */
+  REVO_ERR_CAPACITY = -5,
+  REVO_ERR_LEVEL = -6         /* assert(lvl < size) in imgpyramidrgbd.h:59-94  */
+};
+
+/* TrackerNew::TrackerStatus, tracker.h:61-66 */
+enum {
+  REVO_TRACKER_STATE_OK = 0,
+  REVO_TRACKER_STATE_LOST = 1,
+  REVO_TRACKER_STATE_NEW_KF = 2,
+  REVO_TRACKER_STATE_UNKNOWN = 3
+};
+
+/* ---- settings (POD mirrors of the reference's settings classes) -------- */
+
+/* ImgPyramidSettings, camerapyr.h:27-89 (+ Camera, camerapyr.h:90-111). */
+typedef struct revo_pyr_settings {
+  int32_t width, height;             /* camerapyr.h:49-52 (640x480)          */
+  float fx, fy, cx, cy;              /* camerapyr.h:54-61 (level-0 K)        */
+  int32_t pyr_min_lvl;               /* coarsest level, camerapyr.h:45 (2)   */
+  int32_t pyr_max_lvl;               /* finest level,   camerapyr.h:46 (0); must be 0 */
+  int32_t canny_threshold1;          /* camerapyr.h:40 (150)                 */
+  int32_t canny_threshold2;          /* camerapyr.h:41 (100)                 */
+  float depth_min, depth_max;        /* camerapyr.h:43-44 (0.1, 5.2)         */
+  int32_t use_edge_hist;             /* camerapyr.h:62 (1)                   */
+  float n_percentage;                /* camerapyr.h:63 (0.3)                 */
+  /* distPatchSizes, imgpyramidrgbd.cpp:50: {20,10,5}.  The reference indexes
+   * this 3-entry vector with the level, so levels >= 3 are undefined there;
+   * here 0 means "no histogram / no fill-in at this level". */
+  int32_t hist_patch[REVO_MAX_LEVELS];
+} revo_pyr_settings;
+
+/* OptimizerSettings, optimizer.h:42-112 (only the fields the hot path reads). */
+typedef struct revo_opt_settings {
+  float lambda_success_fac;                  /* optimizer.h:53 (0.5)  */
+  float lambda_fail_fac;                     /* optimizer.h:54 (2.0)  */
+  float lambda_initial[REVO_MAX_LEVELS];     /* optimizer.h:63 (0)    */
+  float step_size_min[REVO_MAX_LEVELS];      /* optimizer.h:55 (1e-16)*/
+  float convergence_eps[REVO_MAX_LEVELS];    /* optimizer.h:65 (0.999)*/
+  int32_t max_its_per_lvl[REVO_MAX_LEVELS];  /* optimizer.h:56 (100)  */
+  float edge_distance_lvl[REVO_MAX_LEVELS];  /* optimizer.h:59 {30,20,10,5,5,5} */
+  float huber_edge;                          /* optimizer.h:75 (0.3)  */
+  int32_t use_edge_filter;                   /* tracker.h:46 (1)      */
+} revo_opt_settings;
+
+/* TrackerSettings, tracker.h:31-55 (+ TrackerNew::histogramLevel, tracker.cpp:229). */
+typedef struct revo_tracker_settings {
+  int32_t check_tracking_results;   /* tracker.h:45 (1) */
+  int32_t check_init_values;        /* tracker.h:43 (1) */
+  int32_t n_frames_hist_voting;     /* tracker.h:47 (3) */
+  int32_t histogram_level;          /* tracker.cpp:229 (2) */
+} revo_tracker_settings;
+
+/* Optimizer::ResidualInfo, optimizer.h:118-140. */
+typedef struct revo_residual_info {
+  int32_t good_pts_edges;
+  int32_t bad_pts_edges;
+  float sum_error_unweighted;
+  float sum_error_weighted;
+} revo_residual_info;
+
+/* Values of config/dataset_tum1.yaml + config/revo_settings.yaml +
+ * OptimizerSettings() defaults. */
+void revo_pyr_settings_default(revo_pyr_settings* s);
+void revo_opt_settings_default(revo_opt_settings* s);
+void revo_tracker_settings_default(revo_tracker_settings* s);
+
+/* ---- handles ------------------------------------------------------------ */
+typedef struct revo_ctx revo_ctx;     /* CameraPyr + TrackerNew + Optimizer state */
+typedef struct revo_pyr revo_pyr;     /* one ImgPyramidRGBD                       */
+typedef struct revo_batch revo_batch; /* B independent frame-pairs, device resident */
+
+const char* revo_last_error(void);
+/* "x.y.z gfx950" */
+const char* revo_version(void);
+
+/* REVO::REVO -> new CameraPyr(settingsPyr) (camerapyr.h:117-164), new
+ * TrackerNew(settingsTracker, settingsPyr) (tracker.cpp:225-235) which owns the
+ * Optimizer (optimizer.cpp:44-61).  device = HIP device ordinal. */
+int revo_ctx_create(int device, const revo_pyr_settings* pyr,
+                    const revo_opt_settings* opt,
+                    const revo_tracker_settings* trk, revo_ctx** out);
+void revo_ctx_destroy(revo_ctx* ctx);
+
+/* Camera(fx,fy,cx,cy,w,h,scale) for level lvl, camerapyr.h:98-103,139-144:
+ * out6 = {fx,fy,cx,cy,width,height}. */
+int revo_ctx_camera(const revo_ctx* ctx, int lvl, float out6[6]);
+
+/* ---- ImgPyramidRGBD ------------------------------------------------------ */
+
+/* ImgPyramidRGBD(settings, camPyr, fullResRgb [BGR8], fullResDepth [f32 metres],
+ * timestamp), imgpyramidrgbd.cpp:43-96.  Inputs are copied before returning
+ * (the reference clones them, cpp:51,54), so the caller may reuse its buffers.
+ * Strides in bytes. */
+int revo_pyramid_create(revo_ctx* ctx, const uint8_t* bgr, size_t bgr_stride,
+                        const float* depth_m, size_t depth_stride,
+                        double timestamp, revo_pyr** out);
+/* Same, fusing iowrapperRGBD.cpp:326-327: depth = u16 * (float)(1/scale). */
+int revo_pyramid_create_u16(revo_ctx* ctx, const uint8_t* bgr, size_t bgr_stride,
+                            const uint16_t* depth_raw, size_t depth_stride,
+                            double depth_scale_factor, double timestamp,
+                            revo_pyr** out);
+/* ~ImgPyramidRGBD, imgpyramidrgbd.cpp:32-41 */
+void revo_pyramid_destroy(revo_pyr* pyr);
+/* ImgPyramidRGBD::makeKeyframe, imgpyramidrgbd.cpp:231-252: exact Euclidean
+ * distance transform + (-dDT/dx, -dDT/dy, DT, 0) float4 table per level. */
+int revo_pyramid_make_keyframe(revo_pyr* pyr);
+int revo_pyramid_is_keyframe(const revo_pyr* pyr);
+double revo_pyramid_timestamp(const revo_pyr* pyr); /* imgpyramidrgbd.h:97-100 */
+
+/* Accessor planes (imgpyramidrgbd.h:45-117). */
+typedef enum revo_plane {
+  REVO_PLANE_GRAY = 0,       /* returnGray(lvl)            u8  W*H            */
+  REVO_PLANE_DEPTH = 1,      /* returnDepth(lvl)           f32 W*H            */
+  REVO_PLANE_EDGES = 2,      /* returnEdges(lvl)           u8  W*H {0,255}    */
+  REVO_PLANE_EDGES_ORIG = 3, /* returnOrigEdges(lvl)       u8  W*H {0,255}    */
+  REVO_PLANE_DT = 4,         /* returnDistTransform(lvl)   f32 W*H (keyframe) */
+  REVO_PLANE_GRADTABLE = 5,  /* returnOptimizationStructure(lvl) f32 4*W*H    */
+  REVO_PLANE_EDGES3D = 6,    /* return3DEdges(lvl)         f32 4*N col-major  */
+  REVO_PLANE_HIST = 7        /* histPyr[lvl]               u8  (H/P)*(W/P)    */
+} revo_plane;
+
+/* Lazy device->host read of one accessor plane.  cap_bytes = size of host_dst;
+ * *count = number of ELEMENTS written (pixels; 3-D points for EDGES3D).
+ * host_dst may be NULL to query *count only. */
+int revo_pyramid_read(revo_pyr* pyr, revo_plane what, int lvl, void* host_dst,
+                      size_t cap_bytes, size_t* count);
+
+/* ---- Optimizer ------------------------------------------------------------ */
+
+/* float Optimizer::trackFrames(ref, curr, R, T, lvl, resInfo),
+ * optimizer.cpp:235-311: the LM loop of ONE pyramid level, run on the device.
+ * R,T in/out; *err = last accepted mean weighted residual. */
+int revo_optimizer_track_level(revo_ctx* ctx, const revo_pyr* ref,
+                               const revo_pyr* curr, float R_colmajor[9],
+                               float T[3], int lvl, revo_residual_info* info,
+                               float* err);
+
+/* Optimizer::calcErrorAndBuffers + calculateWarpUpdate at a fixed pose
+ * (optimizer.cpp:74-234), exposed for parity tests: A (6x6 row==col major,
+ * symmetric), b (6) and error are the LGS6 members after finish()
+ * (LGSX.h:320-326). */
+int revo_optimizer_eval(revo_ctx* ctx, const revo_pyr* ref, const revo_pyr* curr,
+                        const float R_colmajor[9], const float T[3], int lvl,
+                        revo_residual_info* info, float* err, float A[36],
+                        float b[6]);
+
+/* ---- TrackerNew ------------------------------------------------------------ */
+
+/* TrackerStatus TrackerNew::trackFrames(R, T, error, refFrame, currFrame),
+ * tracker.cpp:294-353: init check (265-283, 357-393) + coarse-to-fine loop.
+ * iters_per_lvl (may be NULL) receives the number of residual evaluations
+ * (calls of calcErrorAndBuffers) per level -- the E_l of SURVEY 8(d). */
+int revo_tracker_track_frames(revo_ctx* ctx, const revo_pyr* ref,
+                              const revo_pyr* curr, float R_colmajor[9],
+                              float T[3], float* err, int* status,
+                              revo_residual_info* info,
+                              int32_t iters_per_lvl[REVO_MAX_LEVELS]);
+
+/* TrackerStatus TrackerNew::assessTrackingQuality(estimatedPose, currFrame),
+ * tracker.cpp:118-201.  hist4/overlaps4 (may be NULL) receive the counts. */
+int revo_tracker_assess_quality(revo_ctx* ctx, const float T_w_curr_colmajor[16],
+                                const revo_pyr* curr, int* status,
+                                int32_t hist4[4], int32_t overlaps4[4]);
+/* void TrackerNew::addOldPclAndPose(pcl, worldPose, timeStamp),
+ * tracker.cpp:209-223: pcl = src->return3DEdges(lvl) (kept on the device). */
+int revo_tracker_add_old_pcl(revo_ctx* ctx, const revo_pyr* src, int lvl,
+                             const float T_w_colmajor[16], double timestamp);
+/* void TrackerNew::clearUpPastLists(), tracker.cpp:248-257 */
+int revo_tracker_clear_past(revo_ctx* ctx);
+int revo_tracker_past_size(const revo_ctx* ctx);
+
+/* ---- batched independent frame-pairs (new) -------------------- */
+
+/* One record per pair, 96 bytes. */
+typedef struct revo_pair_result {
+  float R[9];       /* column-major, curr -> ref */
+  float T[3];
+  float err;        /* last level's mean weighted residual */
+  int32_t good, bad;
+  int32_t status;   /* tracker.cpp:351-352 */
+  int32_t evals[REVO_MAX_LEVELS]; /* residual evaluations per level */
+  int32_t flags;    /* bit0: init pose reset to identity (tracker.cpp:277-282);
+                       bit1: non-orthogonal input R */
+  int32_t n_pts0;   /* N_0 of the current frame */
+} revo_pair_result;
+
+/* A batch owns device storage for 2*n_pairs pyramids (ref, curr). */
+int revo_batch_create(revo_ctx* ctx, int n_pairs, revo_batch** out);
+void revo_batch_destroy(revo_batch* b);
+/* Device-resident inputs: d_bgr [2*n_pairs][H][W][3] u8, d_depth
+ * [2*n_pairs][H][W] f32 metres; frame 2*i = reference (keyframe) of pair i,
+ * frame 2*i+1 = current.  h_init_RT: n_pairs x 12 floats (R col-major, T) on
+ * the HOST or NULL for identity.  d_results: n_pairs revo_pair_result records
+ * in DEVICE memory.  stream: hipStream_t (NULL = the batch's own stream).
+ * Enqueues: pyramid build of all frames, keyframe promotion of the refs,
+ * TrackerNew::trackFrames of every pair.  Asynchronous. */
+int revo_batch_track(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
+                     const float* h_init_RT, revo_pair_result* d_results,
+                     void* stream);
+/* Stage-wise variants used by bench.py for per-kernel timing. */
+int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
+                     void* stream);
+int revo_batch_track_only(revo_batch* b, const float* h_init_RT,
+                          revo_pair_result* d_results, void* stream);
+int revo_batch_sync(revo_batch* b, void* stream);
+/* Pyramid view of frame f of the batch (owned by the batch). */
+int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out);
+/* Time one launch of the dominant (tracker) kernel with HIP events on its own
+ * stream: returns the mean duration in ms over `reps` launches. */
+int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT,
+                            revo_pair_result* d_results, void* stream, int reps,
+                            float* ms_mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVO_HIP_H */

@@ -1,0 +1,250 @@
+"""Oracle (CPU restatement) vs independent known answers.  These tests are what
+stands in for the reference's missing tests on cvtColor / pyrDown / Canny /
+distanceTransform / LDLT / SE3."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+import scipy.ndimage as ndi
+
+from oracle import ro
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+rng = np.random.default_rng(1234)
+
+
+def test_bgr2gray_fixed_point():
+    bgr = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    ref = ((bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617
+            + bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(ro.bgr2gray(bgr), ref)
+    # white stays white, primaries follow the Rec.601 weights
+    assert ro.bgr2gray(np.full((2, 2, 3), 255, np.uint8))[0, 0] == 255
+    prim = np.zeros((1, 3, 3), np.uint8)
+    prim[0, 0, 0] = prim[0, 1, 1] = prim[0, 2, 2] = 255
+    assert ro.bgr2gray(prim).tolist() == [[29, 150, 76]]
+
+
+def test_pyrdown_matches_integer_gaussian():
+    g = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    pad = np.pad(g.astype(np.int64), 2, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+    full = np.zeros((48, 64), np.int64)
+    for j in range(5):
+        for i in range(5):
+            full += k[j] * k[i] * pad[j:j + 48, i:i + 64]
+    ref = ((full[::2, ::2] + 128) >> 8).astype(np.uint8)
+    assert np.array_equal(ro.pyrdown(g), ref)
+    assert np.array_equal(ro.pyrdown(np.full((8, 8), 77, np.uint8)), np.full((4, 4), 77, np.uint8))
+
+
+def test_depth_subsample_holes():
+    d = np.array([[1, 0, 2, 2], [0, 0, 2, 4], [0, 0, -1, 3], [0, 0, 0, float("nan")]], np.float32)
+    out = ro.depth_subsample(d)
+    assert out[0, 0] == 1.0 and out[0, 1] == 2.5 and out[1, 0] == 0.0 and out[1, 1] == 3.0
+
+
+def test_sobel_matches_scipy():
+    g = rng.integers(0, 256, (31, 45), dtype=np.uint8)
+    dx, dy = ro.sobel3(g)
+    gi = g.astype(np.int32)
+    sx = ndi.correlate(gi, np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]), mode="nearest")
+    sy = ndi.correlate(gi, np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]]), mode="nearest")
+    assert np.array_equal(dx, sx) and np.array_equal(dy, sy)
+
+
+def _canny_bruteforce(gray, t1, t2):
+    """Independent (slow, python) statement of Canny's definition: NMS survivors above low
+    that are 8-connected to a survivor above high."""
+    lo, hi = sorted((t1, t2))
+    lo, hi = lo * lo, hi * hi
+    h, w = gray.shape
+    dx, dy = ro.sobel3(gray)
+    dx = dx.astype(np.int64)
+    dy = dy.astype(np.int64)
+    mag = np.zeros((h + 2, w + 2), np.int64)
+    mag[1:-1, 1:-1] = dx * dx + dy * dy
+    TG22 = int(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
+    cand = np.zeros((h, w), bool)
+    for y in range(h):
+        for x in range(w):
+            m = mag[y + 1, x + 1]
+            if m <= lo:
+                continue
+            ax, ay = abs(dx[y, x]), abs(dy[y, x]) << 15
+            if ay < ax * TG22:
+                ok = m > mag[y + 1, x] and m >= mag[y + 1, x + 2]
+            elif ay > ax * TG22 + (ax << 16):
+                ok = m > mag[y, x + 1] and m >= mag[y + 2, x + 1]
+            else:
+                s = -1 if (dx[y, x] ^ dy[y, x]) < 0 else 1
+                ok = m > mag[y, x + 1 - s] and m > mag[y + 2, x + 1 + s]
+            cand[y, x] = ok
+    strong = cand & (mag[1:-1, 1:-1] > hi)
+    lab, n = ndi.label(cand, structure=np.ones((3, 3)))
+    keep = np.zeros(n + 1, bool)
+    keep[np.unique(lab[strong])] = True
+    keep[0] = False
+    return np.where(keep[lab], 255, 0).astype(np.uint8)
+
+
+def test_canny_vs_bruteforce_definition():
+    for seed in range(4):
+        r = np.random.default_rng(seed)
+        g = ndi.gaussian_filter(r.uniform(0, 255, (40, 56)), 1.5)
+        g = np.clip((g - g.mean()) * 6 + 128, 0, 255).astype(np.uint8)
+        e = ro.canny(g, 150, 100)
+        assert np.array_equal(e, _canny_bruteforce(g, 150, 100))
+        assert 0 < (e > 0).mean() < 0.5
+
+
+def test_canny_hand_cases():
+    # vertical step of height 60: |dx| = 240 -> strong; edge on exactly one side (> left, >= right)
+    g = np.zeros((12, 16), np.uint8)
+    g[:, 8:] = 60
+    e = ro.canny(g, 150, 100)
+    cols = np.flatnonzero(e.any(0))
+    assert cols.tolist() == [7] and (e[:, 7] == 255).all()
+    # step of 30: |dx| = 120 (weak only, > low but <= high) -> no strong seed -> nothing
+    g[:, 8:] = 30
+    assert ro.canny(g, 150, 100).sum() == 0
+    # weak chain touching a strong segment survives through hysteresis
+    g = np.zeros((20, 16), np.uint8)
+    g[:10, 8:] = 60
+    g[10:, 8:] = 30
+    e = ro.canny(g, 150, 100)
+    assert (e[:, 7] == 255).sum() >= 18
+    # threshold order is irrelevant (swap inside Canny)
+    assert np.array_equal(ro.canny(g, 100, 150), e)
+    # flat image
+    assert ro.canny(np.full((9, 9), 200, np.uint8)).sum() == 0
+
+
+def test_edt_exact_vs_scipy_and_bruteforce():
+    for seed, dens in [(0, 0.02), (1, 0.2), (2, 0.001)]:
+        r = np.random.default_rng(seed)
+        e = np.where(r.uniform(0, 1, (45, 70)) < dens, 255, 0).astype(np.uint8)
+        e[3, 5] = 255
+        dt = ro.edt(e)
+        ref = ndi.distance_transform_edt(e == 0).astype(np.float32)
+        assert np.array_equal(dt, ref)
+        ys, xs = np.nonzero(e)
+        yy, xx = np.mgrid[0:45, 0:70]
+        d2 = ((yy[..., None] - ys) ** 2 + (xx[..., None] - xs) ** 2).min(-1)
+        assert np.array_equal(dt, np.sqrt(d2.astype(np.float32)))
+    # single column / row of edges, edge at the border
+    e = np.zeros((10, 12), np.uint8)
+    e[:, 0] = 255
+    assert np.array_equal(ro.edt(e), np.tile(np.arange(12, dtype=np.float32), (10, 1)))
+    # no edge at all: OpenCV's 1e15 sentinel
+    assert np.all(ro.edt(np.zeros((6, 7), np.uint8)) == np.sqrt(np.float32(1e15)))
+
+
+def test_grad_table_layout():
+    dt = rng.uniform(0, 20, (9, 11)).astype(np.float32)
+    t = ro.grad_table(dt)
+    assert np.all(t[0] == 0) and np.all(t[-1] == 0) and np.all(t[..., 3] == 0)
+    assert np.array_equal(t[1:-1, 1:-1, 0], np.float32(0.5) * (dt[1:-1, :-2] - dt[1:-1, 2:]))
+    assert np.array_equal(t[1:-1, :, 1], np.float32(0.5) * (dt[:-2] - dt[2:]))
+    assert np.array_equal(t[1:-1, :, 2], dt[1:-1])
+    flat = dt.reshape(-1)  # x = 0 wraps to the previous row like the reference's linear sweep
+    assert t[2, 0, 0] == np.float32(0.5) * (flat[2 * 11 - 1] - flat[2 * 11 + 1])
+
+
+def test_histogram_and_edges3d_order():
+    e = np.zeros((20, 40), np.uint8)
+    e[3, 7] = e[4, 7] = e[19, 39] = 255
+    hist, frac = ro.dist_histogram(e, 10)
+    assert hist.tolist() == [[2, 0, 0, 0], [0, 0, 0, 1]] and frac == pytest.approx(2 / 8)
+    # u8 wrap like the reference's ++ on uchar
+    e2 = np.full((20, 20), 255, np.uint8)
+    h2, f2 = ro.dist_histogram(e2, 20)
+    assert h2[0, 0] == (400 % 256)
+    d = np.full((20, 40), 2.0, np.float32)
+    d[4, 7] = 0.0
+    pts = ro.edges3d(e, d, 100.0, 110.0, 20.0, 10.0)
+    assert pts.shape == (2, 4)
+    np.testing.assert_array_equal(pts[0], np.float32([np.float32(2.0) * np.float32(7 - 20.0) / np.float32(100.0),
+                                                      np.float32(2.0) * np.float32(3 - 10.0) / np.float32(110.0), 2.0, 1.0]))
+    # column-major visiting order: x outer, y inner
+    e3 = np.zeros((4, 4), np.uint8)
+    e3[0, 2] = e3[3, 1] = e3[1, 1] = 255
+    p3 = ro.edges3d(e3, np.ones((4, 4), np.float32), 1, 1, 0, 0)
+    assert p3[:, :2].tolist() == [[1, 1], [1, 3], [2, 0]]
+    # invalid depths are skipped
+    d4 = np.float32([[np.nan, np.inf, 0.05, 6.0]])
+    assert ro.edges3d(np.full((1, 4), 255, np.uint8), d4, 1, 1, 0, 0).shape[0] == 0
+
+
+def test_u16_depth_conversion():
+    raw = np.array([[0, 5000, 12345, 65535]], np.uint16)
+    out = ro.u16_to_depth(raw, 5000.0)
+    a = np.float32(1.0 / 5000.0)
+    assert np.array_equal(out, raw.astype(np.float32) * a)
+
+
+def test_ldlt_vs_numpy():
+    for seed in range(6):
+        r = np.random.default_rng(seed)
+        J = r.normal(size=(40, 6)) * np.array([1, 1, 1, 5, 5, 5])
+        A = (J.T @ J / 40).astype(np.float32)
+        b = r.normal(size=6).astype(np.float32)
+        x = ro.ldlt6_solve(A, b)
+        ref = np.linalg.solve(A.astype(np.float64), b.astype(np.float64))
+        assert np.allclose(x, ref, rtol=2e-3, atol=1e-5)
+    # singular: all-zero matrix gives 0 (pseudo-inverse of D)
+    assert np.all(ro.ldlt6_solve(np.zeros((6, 6), np.float32), np.ones(6, np.float32)) == 0)
+
+
+def _hat(v):
+    M = np.zeros((4, 4))
+    M[:3, :3] = [[0, -v[5], v[4]], [v[5], 0, -v[3]], [-v[4], v[3], 0]]
+    M[:3, 3] = v[:3]
+    return M
+
+
+def _oracle_exp_matrix(v):
+    q, t = ro.se3_exp(v)
+    T = np.eye(4)
+    T[:3, :3] = ro.quat_to_R(q)
+    T[:3, 3] = t
+    return T, q, t
+
+
+def test_se3_exp_vs_sophus_golden_and_expm():
+    gold = json.load(open(os.path.join(GOLD, "sophus_se3_golden.json")))
+    for case in gold["exp"]:
+        v = np.array(case["tangent"], np.float64)
+        T, q, _ = _oracle_exp_matrix(v)
+        scale = max(1.0, np.abs(v[:3]).max())
+        assert np.allclose(T, np.array(case["matrix"]), atol=3e-6 * scale), v
+        # the property the reference's own test checks: exp(x) == expm(hat(x)) (tests.hpp:189-211)
+        assert np.allclose(T, scipy.linalg.expm(_hat(v)), atol=3e-6 * scale)
+        assert abs(np.dot(q, q) - 1) < 1e-5  # SO3::exp ENSURE (so3.hpp:559-563)
+    for case in gold["mul"]:
+        qa, ta = ro.se3_exp(np.array(case["a"]))
+        qb, tb = ro.se3_exp(np.array(case["b"]))
+        q, t = ro.se3_mul(qa, ta, qb, tb)
+        T = np.eye(4)
+        T[:3, :3] = ro.quat_to_R(q)
+        T[:3, 3] = t
+        assert np.allclose(T, np.array(case["matrix"]), atol=5e-6)
+
+
+def test_quaternion_roundtrip_and_inverse():
+    for seed in range(5):
+        r = np.random.default_rng(seed)
+        w = r.normal(size=3) * [0.1, 1.0, 3.0][seed % 3]
+        R = scipy.linalg.expm(_hat(np.concatenate([[0, 0, 0], w])))[:3, :3]
+        q = ro.quat_from_R(R)
+        assert np.allclose(ro.quat_to_R(q), R, atol=2e-6)
+        M = np.eye(4)
+        M[:3, :3] = R
+        M[:3, 3] = r.normal(size=3)
+        assert np.allclose(ro.mat4_inverse(M), np.linalg.inv(M), atol=2e-6)
+    Rbad = np.eye(3, dtype=np.float32)
+    Rbad[0, 1] = 1e-3
+    assert ro.lib().ro_is_orthogonal(ro._p(ro._cm3(np.eye(3)), ro.f32p)) == 1
+    assert ro.lib().ro_is_orthogonal(ro._p(ro._cm3(Rbad), ro.f32p)) == 0
