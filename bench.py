@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the REVO hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: for each of the `pairs` independent frame-pairs of this
+rank, build BOTH pyramids (gray, pyrDown, Canny, fill-in, 3-D edge list), promote
+the reference frame to a keyframe (exact EDT + gradient table) and run the full
+coarse-to-fine TrackerNew::trackFrames; with N > 1 ranks the step ends with one
+RCCL all_gather of the 96-byte pair records.  Workload = BASELINE.json configs[2]
+at N = 1 (synthetic 640x480, 4-level pyramid, 32 frame-pairs in flight) and
+configs[4] at N = 8 (256 pairs sharded 32 per GPU): weak scaling.  configs[1]
+(TUM fr1/desk, single stream) cannot run here: no TUM data, no network.
+
+value = tracked frames (= frame-pairs) per second, whole job, max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def render_pair(args):
+    seed, w, h, levels = args
+    from revo_amd import synth
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(w, h, levels)
+    p = synth.make_pair(seed, s)
+    return p["ref"][0], p["ref"][1], p["curr"][0], p["curr"][1], p["T_ref_curr"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="frame-pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- synthetic input (rendered on the host BEFORE any GPU state exists) ----
+    from revo_amd.settings import ImgPyramidSettings, TrackerSettings
+    hist = tuple([20, 10, 5] + [0] * 3) if a.width == 640 else tuple([20, 10, 5, 0, 0, 0])
+    s = ImgPyramidSettings.scaled(a.width, a.height, a.levels, hist_patch=hist)
+    seeds = [rank * a.pairs + i for i in range(a.pairs)]
+    jobs = [(sd, a.width, a.height, a.levels) for sd in seeds]
+    nproc = max(1, min(16, (os.cpu_count() or 1) // max(1, world), a.pairs))
+    t0 = time.time()
+    if nproc > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:
+            rendered = pool.map(render_pair, jobs)
+    else:
+        rendered = [render_pair(j) for j in jobs]
+    t_render = time.time() - t0
+    bgr = np.stack([r[k] for r in rendered for k in (0, 2)])
+    dep = np.stack([r[k] for r in rendered for k in (1, 3)])
+    gt = [r[4] for r in rendered]
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from revo_amd import api, synth
+    cam = api.CameraPyr(s, device=local_rank)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    bt = api.BatchTracker(cam, a.pairs)
+    d_bgr = torch.from_numpy(bgr).to(dev)
+    d_dep = torch.from_numpy(dep).to(dev)
+    d_res = torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev)
+    d_all = torch.zeros(world * a.pairs * 96, dtype=torch.uint8, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        bt.track(d_bgr.data_ptr(), d_dep.data_ptr(), d_res.data_ptr(), stream=stream)
+        if world > 1:  # the only collective: 96 B x pairs per rank, RCCL over xGMI
+            dist.all_gather_into_tensor(d_all, d_res)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- correctness of what was timed (never skipped work): poses vs ground truth
+    res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), a.pairs)
+    errs = [synth.pose_error(r["R"], r["T"], g) for r, g in zip(res, gt)]
+    rot_med = float(np.median([e[0] for e in errs]))
+    tr_med = float(np.median([e[1] for e in errs]))
+
+    # ---- roofline of the dominant kernel (k_track), timed live with HIP events on its stream
+    ms_track = bt.time_tracker(d_res.data_ptr(), reps=10, stream=stream)
+    npts = np.zeros((a.pairs, a.levels), np.int64)
+    for i in range(a.pairs):
+        view = bt.frame(2 * i + 1, s)
+        for lvl in range(a.levels):
+            npts[i, lvl] = view.return3DEdges(lvl).shape[0]
+    evals = np.array([r["evals"][: a.levels] for r in res], np.int64)
+    # B_trk = sum_l E_l*N_l*(16 + 4*16) + init check 2*N_c*(16+4)
+    b_trk = float((evals * npts * 80).sum() + (2 * npts[:, a.levels - 1] * 20).sum())
+    achieved = b_trk / (ms_track * 1e-3) / 1e9  # GB/s
+
+    # stage split (events around build-only / track-only, same stream)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    reps = 5
+    torch.cuda.synchronize()
+    tb = tk = 0.0
+    for _ in range(reps):
+        e0.record()
+        bt.build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream)
+        e1.record()
+        bt.track_only(d_res.data_ptr(), stream=stream)
+        e2.record()
+        torch.cuda.synchronize()
+        tb += e0.elapsed_time(e1)
+        tk += e1.elapsed_time(e2)
+    ms_build, ms_trk_stage = tb / reps, tk / reps
+
+    out = {
+        "metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference",
+        "value": world * a.pairs * a.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic %dx%d RGB-D, %d-level pyramid, %d independent frame-pairs in flight per GPU "
+                        "(BASELINE configs[%d]); per pair: 2 pyramid builds + keyframe (EDT+table) + trackFrames"
+                        % (a.width, a.height, a.levels, a.pairs, 2 if world == 1 else 4),
+            "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
+            "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track,
+        },
+        "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},
+        "pose_error_vs_ground_truth": {"rot_rad_median": rot_med, "trans_m_median": tr_med},
+        "mean_edge_points_lvl0": float(npts[:, 0].mean()),
+        "mean_evals_per_level": [float(x) for x in evals.mean(0)],
+        "input_render_s": t_render,
+    }
+
+    # ---- CPU baseline: the oracle (plain-C port, 1 core) on a bounded sample of the same workload
+    if rank == 0 and world == 1 and a.cpu_baseline != "off":
+        from oracle import ro
+        trk = ro.Tracker(s)
+        done, t0 = 0, time.perf_counter()
+        I3, Z3 = np.eye(3), np.zeros(3)
+        while True:
+            for i in range(a.pairs):
+                o_ref = ro.Pyramid(s, rendered[i][0], rendered[i][1])
+                o_cur = ro.Pyramid(s, rendered[i][2], rendered[i][3])
+                o_ref.makeKeyframe()
+                trk.trackFrames(o_ref, o_cur, I3, Z3)
+                done += 1
+                if time.perf_counter() - t0 > a.cpu_seconds and done >= 8:
+                    break
+            if time.perf_counter() - t0 > a.cpu_seconds and done >= 8:
+                break
+        cpu_t = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": done / cpu_t, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frame-pairs of the same batch (2 pyramids + keyframe + trackFrames each), oracle/ "
+                      "plain-C restatement, gcc -O3 -mavx2, 1 thread, %.1f s" % (done, cpu_t),
+        }
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

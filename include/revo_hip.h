@@ -124,6 +124,11 @@ int revo_ctx_create(int device, const revo_pyr_settings* pyr,
                     const revo_opt_settings* opt,
                     const revo_tracker_settings* trk, revo_ctx** out);
 void revo_ctx_destroy(revo_ctx* ctx);
+/* TrackerNew(const TrackerSettings&, const ImgPyramidSettings&) (tracker.cpp:225-235)
+ * is constructed AFTER CameraPyr and the IO thread in the reference
+ * (system.cpp:96,107): applies tracker/optimizer settings to an existing ctx. */
+int revo_ctx_set_tracker(revo_ctx* ctx, const revo_opt_settings* opt,
+                         const revo_tracker_settings* trk);
 
 /* Camera(fx,fy,cx,cy,w,h,scale) for level lvl, camerapyr.h:98-103,139-144:
  * out6 = {fx,fy,cx,cy,width,height}. */

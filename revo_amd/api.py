@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's hot-path classes over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference so the parity
+tests read like tests of the reference itself:
+
+  CameraPyr        datastructures/camerapyr.h:113-193   (owns the device context)
+  ImgPyramidRGBD   datastructures/imgpyramidrgbd.h:27-250
+  Optimizer        system/optimizer.h:114-186
+  TrackerNew       system/tracker.h:56-105
+  BatchTracker     new: B independent frame-pairs resident in HBM
+
+numpy matrices are ordinary row-major views (R[i, j]); the column-major
+conversion the C ABI wants (Eigen storage) happens here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RevoError, check, f32p, i32p, u8p, u16p, vp
+from .settings import (ImgPyramidSettings, OptimizerSettings, TrackerSettings, ResidualInfo, PairResult,
+                       MAX_LEVELS, PLANE_GRAY, PLANE_DEPTH, PLANE_EDGES, PLANE_EDGES_ORIG, PLANE_DT,
+                       PLANE_GRADTABLE, PLANE_EDGES3D, PLANE_HIST, TRACKER_STATE_OK, TRACKER_STATE_NEW_KF)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _cm3(R):
+    return np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)
+
+
+def _cm4(M):
+    return np.ascontiguousarray(np.asarray(M, np.float32).T).reshape(16)
+
+
+class Camera:
+    """camerapyr.h:90-111"""
+
+    def __init__(self, fx, fy, cx, cy, width, height):
+        self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
+        self.width, self.height = int(width), int(height)
+        self.area = self.width * self.height
+
+    def returnSize(self):
+        return (self.width, self.height)
+
+
+class CameraPyr:
+    """camerapyr.h:113-193.  Also owns the HIP context (device, stream, HBM pools)."""
+
+    def __init__(self, settingsPyr, device=0, optimizerSettings=None, trackerSettings=None):
+        self.settings = settingsPyr
+        self._h = vp()
+        opt = optimizerSettings or OptimizerSettings()
+        trk = trackerSettings or TrackerSettings()
+        check(_lib.lib().revo_ctx_create(device, C.byref(settingsPyr), C.byref(opt), C.byref(trk), C.byref(self._h)))
+        self.camPyr = []
+        for lvl in range(settingsPyr.nLevels()):
+            out = np.empty(6, np.float32)
+            check(_lib.lib().revo_ctx_camera(self._h, lvl, _p(out, f32p)))
+            self.camPyr.append(Camera(*[float(x) for x in out[:4]], out[4], out[5]))
+
+    def size(self):
+        return len(self.camPyr)
+
+    def at(self, lvl):
+        return self.camPyr[lvl]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().revo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DT = {PLANE_GRAY: (np.uint8, 1), PLANE_DEPTH: (np.float32, 1), PLANE_EDGES: (np.uint8, 1),
+       PLANE_EDGES_ORIG: (np.uint8, 1), PLANE_DT: (np.float32, 1), PLANE_GRADTABLE: (np.float32, 4),
+       PLANE_EDGES3D: (np.float32, 4), PLANE_HIST: (np.uint8, 1)}
+
+
+class ImgPyramidRGBD:
+    """imgpyramidrgbd.h:27-250.  fullResRgb is BGR8 [H,W,3], fullResDepth float32 metres [H,W]
+    (or uint16 raw + depth_scale_factor, fusing iowrapperRGBD.cpp:326-327)."""
+
+    def __init__(self, settings, cameraPyr, fullResRgb=None, fullResDepth=None, timestamp=0.0,
+                 depth_scale_factor=None, _handle=None, _owned=True):
+        self.mSettings = settings
+        self.cameraPyr = cameraPyr
+        self.frameId = 0
+        self._owned = _owned
+        self._T_w_f = np.eye(4, dtype=np.float32)
+        if _handle is not None:
+            self._h = _handle
+            return
+        bgr = np.ascontiguousarray(fullResRgb, np.uint8)
+        h, w = bgr.shape[:2]
+        if bgr.shape != (h, w, 3) or np.shape(fullResDepth) != (h, w) or (w, h) != (settings.width, settings.height):
+            raise ValueError("image size does not match the settings")
+        self._h = vp()
+        L = _lib.lib()
+        if depth_scale_factor is not None:
+            d = np.ascontiguousarray(fullResDepth, np.uint16)
+            check(L.revo_pyramid_create_u16(cameraPyr._h, _p(bgr, u8p), w * 3, _p(d, u16p), w * 2,
+                                            float(depth_scale_factor), float(timestamp), C.byref(self._h)))
+        else:
+            d = np.ascontiguousarray(fullResDepth, np.float32)
+            check(L.revo_pyramid_create(cameraPyr._h, _p(bgr, u8p), w * 3, _p(d, f32p), w * 4, float(timestamp),
+                                        C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._owned and getattr(self, "_h", None):
+                _lib.lib().revo_pyramid_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- keyframe promotion (imgpyramidrgbd.cpp:231-252)
+    def makeKeyframe(self):
+        check(_lib.lib().revo_pyramid_make_keyframe(self._h))
+
+    def _read(self, what, lvl):
+        dt, k = _DT[what]
+        n = C.c_size_t()
+        check(_lib.lib().revo_pyramid_read(self._h, what, lvl, None, 0, C.byref(n)))
+        buf = np.empty((n.value, k) if k > 1 else (n.value,), dt)
+        if n.value:
+            check(_lib.lib().revo_pyramid_read(self._h, what, lvl, buf.ctypes.data_as(vp), buf.nbytes, C.byref(n)))
+        w, h = self.mSettings.level_size(lvl)
+        if what == PLANE_EDGES3D or n.value == 0:
+            return buf
+        if what == PLANE_HIST:
+            p = self.mSettings.hist_patch[lvl]
+            return buf.reshape(h // p, w // p)
+        return buf.reshape((h, w, 4) if k > 1 else (h, w))
+
+    # -- accessors (imgpyramidrgbd.h:45-117)
+    def returnK(self, lvl):
+        cam = self.cameraPyr.at(lvl)
+        K = np.eye(3, dtype=np.float32)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = cam.fx, cam.fy, cam.cx, cam.cy
+        return K
+
+    def returnDistTransform(self, lvl):
+        return self._read(PLANE_DT, lvl)
+
+    def returnEdges(self, lvl):
+        return self._read(PLANE_EDGES, lvl)
+
+    def returnOrigEdges(self, lvl):
+        return self._read(PLANE_EDGES_ORIG, lvl)
+
+    def return3DEdges(self, lvl):
+        """N x 4 float32 rows (X,Y,Z,1) == the columns of the reference's 4xN Eigen::MatrixXf."""
+        return self._read(PLANE_EDGES3D, lvl)
+
+    def returnDepth(self, lvl):
+        return self._read(PLANE_DEPTH, lvl)
+
+    def returnGray(self, lvl):
+        return self._read(PLANE_GRAY, lvl)
+
+    def returnOptimizationStructure(self, lvl):
+        return self._read(PLANE_GRADTABLE, lvl)
+
+    def returnHist(self, lvl):
+        return self._read(PLANE_HIST, lvl)
+
+    def returnTimestamp(self):
+        return _lib.lib().revo_pyramid_timestamp(self._h)
+
+    def returnMaxLvl(self):
+        return self.mSettings.pyr_max_lvl
+
+    def returnMinLvl(self):
+        return self.mSettings.pyr_min_lvl
+
+    def isKeyframe(self):
+        return bool(_lib.lib().revo_pyramid_is_keyframe(self._h))
+
+    # -- pose bookkeeping (imgpyramidrgbd.h:126-151): plain host state
+    def setTwf(self, T):
+        self._T_w_f = np.array(T, np.float32).reshape(4, 4)
+
+    def getTransKFtoWorld(self):
+        return self._T_w_f
+
+    def prepareKfForStorage(self):  # imgpyramidrgbd.h:156-169: effectively a no-op in the reference
+        return None
+
+
+class Optimizer:
+    """system/optimizer.h:114-186 (the LM loop of one level runs on the device)."""
+
+    ResidualInfo = ResidualInfo
+
+    def __init__(self, settings, cameraPyr):
+        self.mSettings = settings
+        self._cam = cameraPyr
+
+    def trackFrames(self, refFrame, currFrame, R, T, lvl, resInfo=None):
+        """-> (last_residual, R, T): optimizer.cpp:235-311."""
+        Rc, Tc = _cm3(R), np.array(T, np.float32).reshape(3)
+        info = resInfo if resInfo is not None else ResidualInfo()
+        err = C.c_float()
+        check(_lib.lib().revo_optimizer_track_level(self._cam._h, refFrame._h, currFrame._h, _p(Rc, f32p),
+                                                    _p(Tc, f32p), lvl, C.byref(info), C.byref(err)))
+        return err.value, Rc.reshape(3, 3).T.copy(), Tc
+
+    def evalAt(self, refFrame, currFrame, R, T, lvl):
+        """calcErrorAndBuffers + calculateWarpUpdate at a fixed pose -> (err, info, A[6,6], b[6])."""
+        Rc, Tc = _cm3(R), np.ascontiguousarray(T, np.float32).reshape(3)
+        info = ResidualInfo()
+        err = C.c_float()
+        A = np.empty(36, np.float32)
+        b = np.empty(6, np.float32)
+        check(_lib.lib().revo_optimizer_eval(self._cam._h, refFrame._h, currFrame._h, _p(Rc, f32p), _p(Tc, f32p), lvl,
+                                             C.byref(info), C.byref(err), _p(A, f32p), _p(b, f32p)))
+        return err.value, info, A.reshape(6, 6), b
+
+
+class TrackerNew:
+    """system/tracker.h:56-105."""
+
+    TRACKER_STATE_OK, TRACKER_STATE_LOST, TRACKER_STATE_NEW_KF, TRACKER_STATE_UNKNOWN = 0, 1, 2, 3
+
+    def __init__(self, config, pyrConfig, cameraPyr):
+        self.mSettings = config
+        self.mPyrConfig = pyrConfig
+        self._cam = cameraPyr
+        self.optimizerSettings = getattr(config, "optimizerSettings", None) or OptimizerSettings()
+        check(_lib.lib().revo_ctx_set_tracker(cameraPyr._h, C.byref(self.optimizerSettings), C.byref(config)))
+        self.histogramLevel = config.histogram_level
+        self.mOptimizer = Optimizer(self.optimizerSettings, cameraPyr)
+        self.last_evals = np.zeros(MAX_LEVELS, np.int32)
+        self.last_info = ResidualInfo()
+
+    def trackFrames(self, R, T, refFrame, currFrame):
+        """-> (status, R, T, error): tracker.cpp:294-353."""
+        Rc, Tc = _cm3(R), np.array(T, np.float32).reshape(3)
+        err, status = C.c_float(), C.c_int()
+        evals = np.zeros(MAX_LEVELS, np.int32)
+        info = ResidualInfo()
+        check(_lib.lib().revo_tracker_track_frames(self._cam._h, refFrame._h, currFrame._h, _p(Rc, f32p), _p(Tc, f32p),
+                                                   C.byref(err), C.byref(status), C.byref(info), _p(evals, i32p)))
+        self.last_evals, self.last_info = evals, info
+        return status.value, Rc.reshape(3, 3).T.copy(), Tc, err.value
+
+    def assessTrackingQuality(self, estimatedPose, currFrame, return_hist=False):
+        Mc = _cm4(estimatedPose)
+        st = C.c_int()
+        h4 = np.zeros(4, np.int32)
+        o4 = np.zeros(4, np.int32)
+        check(_lib.lib().revo_tracker_assess_quality(self._cam._h, _p(Mc, f32p), currFrame._h, C.byref(st), _p(h4, i32p),
+                                                     _p(o4, i32p)))
+        return (st.value, h4, o4) if return_hist else st.value
+
+    def addOldPclAndPose(self, srcFrame, lvl, worldPose, timeStamp=0.0):
+        """tracker.cpp:209-223; the cloud is srcFrame.return3DEdges(lvl) and stays in HBM."""
+        Mc = _cm4(worldPose)
+        check(_lib.lib().revo_tracker_add_old_pcl(self._cam._h, srcFrame._h, lvl, _p(Mc, f32p), float(timeStamp)))
+
+    def clearUpPastLists(self):
+        check(_lib.lib().revo_tracker_clear_past(self._cam._h))
+
+    def pastSize(self):
+        return _lib.lib().revo_tracker_past_size(self._cam._h)
+
+
+class BatchTracker:
+    """B independent frame-pairs resident in HBM: pyramids of all 2B frames, keyframe
+    promotion of the B references and TrackerNew::trackFrames of every pair, enqueued on
+    one stream without host round trips.  Inputs/outputs are raw device pointers (e.g.
+    torch tensors' data_ptr())."""
+
+    def __init__(self, cameraPyr, n_pairs):
+        self._cam = cameraPyr
+        self.n_pairs = n_pairs
+        self._h = vp()
+        check(_lib.lib().revo_batch_create(cameraPyr._h, n_pairs, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().revo_batch_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _init(init_RT):
+        if init_RT is None:
+            return None, None
+        a = np.ascontiguousarray(init_RT, np.float32)
+        return a, _p(a, f32p)
+
+    def track(self, d_bgr, d_depth, d_results, init_RT=None, stream=None):
+        keep, ptr = self._init(init_RT)
+        check(_lib.lib().revo_batch_track(self._h, d_bgr, d_depth, ptr, d_results, stream))
+
+    def build(self, d_bgr, d_depth, stream=None):
+        check(_lib.lib().revo_batch_build(self._h, d_bgr, d_depth, stream))
+
+    def track_only(self, d_results, init_RT=None, stream=None):
+        keep, ptr = self._init(init_RT)
+        check(_lib.lib().revo_batch_track_only(self._h, ptr, d_results, stream))
+
+    def sync(self, stream=None):
+        check(_lib.lib().revo_batch_sync(self._h, stream))
+
+    def frame(self, f, settings):
+        h = vp()
+        check(_lib.lib().revo_batch_frame(self._h, f, C.byref(h)))
+        return ImgPyramidRGBD(settings, self._cam, _handle=h, _owned=False)
+
+    def time_tracker(self, d_results, reps=5, init_RT=None, stream=None):
+        keep, ptr = self._init(init_RT)
+        ms = C.c_float()
+        check(_lib.lib().revo_batch_time_tracker(self._h, ptr, d_results, stream, reps, C.byref(ms)))
+        return ms.value
+
+
+def pack_init_RT(Rs, Ts):
+    """list of (R 3x3 row-major numpy, T) -> n x 12 float32 (R column-major, T) for BatchTracker."""
+    out = np.empty((len(Rs), 12), np.float32)
+    for i, (R, T) in enumerate(zip(Rs, Ts)):
+        out[i, :9] = _cm3(R)
+        out[i, 9:] = np.asarray(T, np.float32)
+    return out
+
+
+def results_from_buffer(buf, n):
+    """bytes / uint8 numpy of n revo_pair_result records -> list of dicts."""
+    arr = (PairResult * n).from_buffer_copy(bytes(buf))
+    out = []
+    for r in arr:
+        out.append(dict(R=np.array(r.R, np.float32).reshape(3, 3).T.copy(), T=np.array(r.T, np.float32),
+                        err=r.err, good=r.good, bad=r.bad, status=r.status,
+                        evals=np.array(r.evals, np.int32), flags=r.flags, n_pts0=r.n_pts0))
+    return out

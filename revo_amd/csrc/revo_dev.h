@@ -1,0 +1,114 @@
+// revo_dev.h -- shared host/device declarations of librevo_hip.so (gfx950 only).
+//
+// HBM layout.  A FrameSet holds B frames.  Every per-level plane is stored
+// level-major with the frame as the slow index inside the level:
+//     plane[l] + f * P_l      (P_l = w_l * h_l elements)
+// so one launch covers all frames (blockIdx.z = frame) and, where levels are
+// independent, all levels (blockIdx.x decodes level + tile).  A single
+// ImgPyramidRGBD is a FrameSet with B = 1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/revo_hip.h"
+
+#define REVO_L REVO_MAX_LEVELS
+
+struct LevelGeom {
+  int w, h;            // Camera(...,scale) width/height, camerapyr.h:98-103
+  int npix;            // w*h
+  float fx, fy, cx, cy;
+  int patch;           // distPatchSizes[l] (0 = none), imgpyramidrgbd.cpp:50
+  int hist_w, hist_h;  // w/patch, h/patch
+  int nchunk;          // row-chunks per column for the ordered compaction
+  int chunk_rows;
+  // launch decode helpers (prefix sums over levels)
+  int tile_base;       // first 64x16 tile index of this level
+  int tiles_x, tiles_y;
+  int pix_base;        // sum of npix of finer levels
+  int row_base;        // sum of h of finer levels
+  int col_base;        // sum of w of finer levels
+  int cc_base;         // sum of w*nchunk of finer levels
+};
+
+struct PyrGeom {
+  int n_levels;
+  int total_tiles, total_pix, total_rows, total_cols, total_cc;
+  float depth_min, depth_max;
+  int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
+  int use_edge_hist;
+  float n_percentage;
+  double fill_thr[REVO_L];    // PATCH_SIZE_2*0.05, imgpyramidrgbd.cpp:133
+  LevelGeom lv[REVO_L];
+};
+
+// Base pointers of one FrameSet (frame stride = lv[l].npix elements unless noted).
+struct FramePlanes {
+  uint8_t* gray[REVO_L];
+  float* depth[REVO_L];
+  uint8_t* nms[REVO_L];        // Canny map: 0 none, 1 weak candidate, 2 strong
+  uint8_t* edges[REVO_L];      // edgesPyr     {0,255}
+  uint8_t* edges_orig[REVO_L]; // edgesOrigPyr {0,255}
+  int* scratch[REVO_L];        // CCL parent keys during the build; column g^2 during makeKeyframe
+  float4* pts[REVO_L];         // edges3DPyr: (X,Y,Z,1), capacity npix per frame
+  float* dt[REVO_L];           // dtPyr
+  float4* table[REVO_L];       // optimizationStructure
+  uint8_t* hist[REVO_L];       // histPyr (frame stride hist_w*hist_h)
+  int* chunk[REVO_L];          // compaction counts -> offsets (frame stride w*nchunk)
+  int* npts;                   // [B][REVO_L]
+  int* hist_nz;                // [B][REVO_L]
+};
+
+// One frame-pair for the tracker kernel.
+struct PairDesc {
+  const float4* pts[REVO_L];    // current frame's 3-D edge lists
+  const int* npts;              // -> int[REVO_L] of the current frame
+  const float4* table[REVO_L];  // keyframe's gradient/DT table
+  const float* dt_coarse;       // keyframe's DT at pyr_min_lvl (init check)
+  float R[9];                   // initial R (column-major), curr -> ref
+  float T[3];
+};
+
+struct TrackParams {
+  int pyr_min_lvl, pyr_max_lvl;   // coarse-to-fine range, tracker.cpp:324
+  int lvl_begin, lvl_end;         // levels to run (lvl_begin >= lvl_end), inclusive
+  int check_init;                 // tracker.cpp:268
+  int eval_only;                  // 1: one calcErrorAndBuffers+calculateWarpUpdate at (R,T), lvl_begin
+  float lambda_success_fac, lambda_fail_fac;
+  float lambda_initial[REVO_L], step_size_min[REVO_L], convergence_eps[REVO_L];
+  int max_its[REVO_L];
+  float edge_distance[REVO_L];
+  float huber_edge;
+  int use_edge_filter;
+  struct { float fx, fy, cx, cy; int w, h; } cam[REVO_L];
+};
+
+// eval_only output (parity tests): LGS6 after finish() + ResidualInfo
+struct EvalOut {
+  float A[36];
+  float b[6];
+  float error;      // ls.error
+  float mean_err;   // return value of calcErrorAndBuffers
+  float sum_w, sum_u;
+  int good, bad;
+};
+
+#define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
+#define NMS_TILE_W 64
+#define NMS_TILE_H 16
+#define TRACK_THREADS 1024
+
+// ---- launchers (defined in the kernel translation units) -------------------
+void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,
+                       const uint16_t* d_depth_u16, float u16_alpha, int B, hipStream_t s);
+void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s);
+void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+// keyframe promotion of frames f0, f0+fstride, ... (count frames)
+void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
+void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
+                  int n_pairs, hipStream_t s);
+void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds,
+                 const float4* const* d_cloud_pts, const int* const* d_cloud_n, const float* d_RT /*n x 12*/,
+                 int* d_marks /*npix*/, int* d_hist8 /*hist[4], overlaps[4]*/, int use_orig_edges, hipStream_t s);

@@ -1,0 +1,731 @@
+// revo_host.hip -- host side of librevo_hip.so: the C ABI of include/revo_hip.h.
+//
+// Owns HBM (one blob per FrameSet, pooled), the per-context HIP stream, and the
+// sequencing of the kernels in revo_pyramid.hip / revo_track.hip.  No torch, no
+// Eigen, no OpenCV types cross this boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "revo_dev.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local std::string g_err;
+extern "C" const char* revo_last_error(void) { return g_err.c_str(); }
+extern "C" const char* revo_version(void) { return "0.1.0 gfx950"; }
+
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHECK(expr)                                                                      \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail(REVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+// ---------------------------------------------------------------- defaults --
+extern "C" void revo_pyr_settings_default(revo_pyr_settings* s) {  // config/dataset_tum1.yaml
+  memset(s, 0, sizeof(*s));
+  s->width = 640; s->height = 480;
+  s->fx = 517.306408f; s->fy = 516.469215f; s->cx = 318.643040f; s->cy = 255.313989f;
+  s->pyr_min_lvl = 2; s->pyr_max_lvl = 0;
+  s->canny_threshold1 = 150; s->canny_threshold2 = 100;
+  s->depth_min = 0.1f; s->depth_max = 5.2f;
+  s->use_edge_hist = 1; s->n_percentage = 0.3f;
+  s->hist_patch[0] = 20; s->hist_patch[1] = 10; s->hist_patch[2] = 5;  // imgpyramidrgbd.cpp:50
+}
+extern "C" void revo_opt_settings_default(revo_opt_settings* s) {  // optimizer.h:46-85
+  memset(s, 0, sizeof(*s));
+  s->lambda_success_fac = 0.5f; s->lambda_fail_fac = 2.0f;
+  const float ed[6] = {30, 20, 10, 5, 5, 5};
+  for (int i = 0; i < REVO_L; ++i) {
+    s->lambda_initial[i] = 0.f; s->step_size_min[i] = 1e-16f; s->convergence_eps[i] = 0.999f;
+    s->max_its_per_lvl[i] = 100; s->edge_distance_lvl[i] = ed[i];
+  }
+  s->huber_edge = 0.3f;
+  s->use_edge_filter = 1;  // config/revo_settings.yaml:11
+}
+extern "C" void revo_tracker_settings_default(revo_tracker_settings* s) {  // config/revo_settings.yaml:9-12
+  s->check_tracking_results = 1; s->check_init_values = 1; s->n_frames_hist_voting = 3;
+  s->histogram_level = 2;  // tracker.cpp:229
+}
+
+// ----------------------------------------------------------------- objects --
+struct FrameSet {
+  int B = 0;
+  void* blob = nullptr;
+  size_t blob_bytes = 0;
+  FramePlanes p{};
+  uint8_t* d_bgr = nullptr;   // input staging (single-frame API)
+  float* d_depth = nullptr;   // input staging; aliased as u16 for the u16 entry point
+};
+
+struct Past {  // one entry of mPastPcl / mPastWorldPoses / mPastTimeStamps (tracker.h:92-95)
+  float4* d_pts; int* d_n; int n; float T_w[16]; double ts;
+};
+
+struct revo_ctx {
+  int device;
+  revo_pyr_settings ps; revo_opt_settings os; revo_tracker_settings ts;
+  PyrGeom geom;
+  TrackParams tp;
+  hipStream_t stream;
+  std::mutex mu;
+  std::vector<FrameSet*> pool;  // free single-frame FrameSets
+  // single-pair tracker scratch
+  PairDesc* h_desc; PairDesc* d_desc;
+  revo_pair_result* h_res; revo_pair_result* d_res;
+  EvalOut* h_eval; EvalOut* d_eval;
+  // vote
+  std::deque<Past> past;
+  int* d_marks; int* d_hist8; int* h_hist8;
+  const float4** d_cloud_pts; const int** d_cloud_n; float* d_RT;
+  const float4** h_cloud_pts; const int** h_cloud_n; float* h_RT;
+};
+
+struct revo_pyr {
+  revo_ctx* ctx;
+  FrameSet* fs;
+  int frame;
+  bool owns_fs;
+  bool is_kf;
+  double ts;
+};
+
+struct revo_batch {
+  revo_ctx* ctx;
+  int n_pairs;
+  FrameSet* fs;
+  std::vector<revo_pyr> views;
+  PairDesc* h_descs; PairDesc* d_descs;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+};
+
+// ---------------------------------------------------------------- geometry --
+static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) {
+  memset(g, 0, sizeof(*g));
+  const int L = s.pyr_min_lvl - s.pyr_max_lvl + 1;  // camerapyr.h:68-71
+  if (s.pyr_max_lvl != 0) { *why = "pyr_max_lvl must be 0 (the reference indexes per-level vectors by level)"; return -1; }
+  if (L < 1 || L > REVO_L) { *why = "1..6 pyramid levels supported"; return -1; }
+  if (s.width <= 0 || s.height <= 0 || s.width > REVO_MAX_WIDTH) { *why = "bad image size"; return -1; }
+  if (s.width % (4 << (L - 1)) || s.height % (1 << (L - 1))) {
+    *why = "width must be a multiple of 4*2^(levels-1) and height of 2^(levels-1)"; return -1;
+  }
+  g->n_levels = L;
+  g->depth_min = s.depth_min; g->depth_max = s.depth_max;
+  // cv::Canny with L2gradient: low/high swapped if needed, squared (imgpyramidrgbd.cpp:184)
+  double lo = s.canny_threshold1, hi = s.canny_threshold2;
+  if (lo > hi) std::swap(lo, hi);
+  lo = std::min(32767.0, lo); hi = std::min(32767.0, hi);
+  if (lo > 0) lo *= lo;
+  if (hi > 0) hi *= hi;
+  g->canny_low = (int)std::floor(lo); g->canny_high = (int)std::floor(hi);
+  g->use_edge_hist = s.use_edge_hist; g->n_percentage = s.n_percentage;
+  int tile = 0, pix = 0, row = 0, col = 0, cc = 0;
+  for (int l = 0; l < L; ++l) {
+    LevelGeom& v = g->lv[l];
+    const float scale = 1.0f / (float)std::pow(2, l);  // camerapyr.h:142
+    if (l == 0) { v.fx = s.fx; v.fy = s.fy; v.cx = s.cx; v.cy = s.cy; v.w = s.width; v.h = s.height; }
+    else {
+      v.fx = s.fx * scale; v.fy = s.fy * scale; v.cx = s.cx * scale; v.cy = s.cy * scale;
+      v.w = (int)((float)s.width * scale); v.h = (int)((float)s.height * scale);
+    }
+    v.npix = v.w * v.h;
+    v.patch = s.hist_patch[l] > 0 ? s.hist_patch[l] : 0;
+    if (v.patch > 0) {
+      v.hist_w = v.w / v.patch; v.hist_h = v.h / v.patch;
+      if (v.hist_w < 1 || v.hist_h < 1 || v.hist_w > 128) { *why = "hist_patch out of range for this level size"; return -1; }
+    }
+    g->fill_thr[l] = (double)(v.patch * v.patch) * 0.05;  // imgpyramidrgbd.cpp:133
+    v.chunk_rows = 32; v.nchunk = (v.h + 31) / 32;
+    v.tiles_x = (v.w + NMS_TILE_W - 1) / NMS_TILE_W; v.tiles_y = (v.h + NMS_TILE_H - 1) / NMS_TILE_H;
+    v.tile_base = tile; tile += v.tiles_x * v.tiles_y;
+    v.pix_base = pix; pix += v.npix;
+    v.row_base = row; row += v.h;
+    v.col_base = col; col += v.w;
+    v.cc_base = cc; cc += v.w * v.nchunk;
+  }
+  g->total_tiles = tile; g->total_pix = pix; g->total_rows = row; g->total_cols = col; g->total_cc = cc;
+  return 0;
+}
+
+static void build_track_params(const revo_ctx* c, TrackParams* t) {
+  memset(t, 0, sizeof(*t));
+  t->pyr_min_lvl = c->ps.pyr_min_lvl; t->pyr_max_lvl = c->ps.pyr_max_lvl;
+  t->lvl_begin = c->ps.pyr_min_lvl; t->lvl_end = c->ps.pyr_max_lvl;
+  t->check_init = c->ts.check_init_values;
+  t->lambda_success_fac = c->os.lambda_success_fac; t->lambda_fail_fac = c->os.lambda_fail_fac;
+  for (int i = 0; i < REVO_L; ++i) {
+    t->lambda_initial[i] = c->os.lambda_initial[i]; t->step_size_min[i] = c->os.step_size_min[i];
+    t->convergence_eps[i] = c->os.convergence_eps[i]; t->max_its[i] = c->os.max_its_per_lvl[i];
+    t->edge_distance[i] = c->os.edge_distance_lvl[i];
+  }
+  t->huber_edge = c->os.huber_edge; t->use_edge_filter = c->os.use_edge_filter;
+  for (int l = 0; l < c->geom.n_levels; ++l) {
+    const LevelGeom& v = c->geom.lv[l];
+    t->cam[l].fx = v.fx; t->cam[l].fy = v.fy; t->cam[l].cx = v.cx; t->cam[l].cy = v.cy; t->cam[l].w = v.w; t->cam[l].h = v.h;
+  }
+}
+
+// --------------------------------------------------------------- FrameSets --
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out) {
+  const PyrGeom& g = c->geom;
+  FrameSet* fs = new FrameSet();
+  fs->B = B;
+  // pass 1: size, pass 2: carve
+  for (int pass = 0; pass < 2; ++pass) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> void* {
+      void* p = pass ? (void*)((char*)fs->blob + off) : nullptr;
+      off = align_up(off + bytes, 256);
+      return p;
+    };
+    for (int l = 0; l < g.n_levels; ++l) {
+      const LevelGeom& v = g.lv[l];
+      const size_t n = (size_t)v.npix * B;
+      fs->p.gray[l] = (uint8_t*)take(n);
+      fs->p.depth[l] = (float*)take(n * 4);
+      fs->p.nms[l] = (uint8_t*)take(n);
+      fs->p.edges[l] = (uint8_t*)take(n);
+      fs->p.edges_orig[l] = (uint8_t*)take(n);
+      fs->p.scratch[l] = (int*)take(n * 4);
+      fs->p.pts[l] = (float4*)take(n * 16);
+      fs->p.dt[l] = (float*)take(n * 4);
+      fs->p.table[l] = (float4*)take(n * 16);
+      fs->p.hist[l] = (uint8_t*)take((size_t)std::max(1, v.hist_w * v.hist_h) * B);
+      fs->p.chunk[l] = (int*)take((size_t)v.w * v.nchunk * B * 4);
+    }
+    fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
+    fs->p.hist_nz = (int*)take(sizeof(int) * REVO_L * B);
+    if (with_staging) {
+      fs->d_bgr = (uint8_t*)take((size_t)g.lv[0].npix * 3 * B);
+      fs->d_depth = (float*)take((size_t)g.lv[0].npix * 4 * B);
+    }
+    if (!pass) {
+      fs->blob_bytes = off;
+      hipError_t e = hipMalloc(&fs->blob, off);
+      if (e != hipSuccess) { delete fs; return fail(REVO_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    }
+  }
+  // counts start at zero so an accessor on a not-yet-built pyramid is well defined
+  hipMemsetAsync(fs->p.npts, 0, sizeof(int) * REVO_L * B, c->stream);
+  *out = fs;
+  return REVO_OK;
+}
+static void frameset_destroy(FrameSet* fs) {
+  if (!fs) return;
+  if (fs->blob) hipFree(fs->blob);
+  delete fs;
+}
+
+// enqueue the full per-frame build (imgpyramidrgbd.cpp:43-96) for all B frames
+static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
+                          const uint16_t* d_depth_u16, float alpha, hipStream_t s) {
+  const PyrGeom& g = c->geom;
+  launch_gray_depth(g, fs->p, d_bgr, d_depth_f32, d_depth_u16, alpha, fs->B, s);
+  for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, fs->B, s);
+  launch_canny_nms(g, fs->p, fs->B, s);
+  launch_ccl(g, fs->p, fs->B, s);
+  launch_hist_fill(g, fs->p, fs->B, s);
+  launch_compact(g, fs->p, fs->B, s);
+}
+
+// ------------------------------------------------------------------ context --
+extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const revo_opt_settings* opt,
+                               const revo_tracker_settings* trk, revo_ctx** out) {
+  if (!pyr || !out) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(REVO_ERR_HIP, "no HIP device: librevo_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(REVO_ERR_INVALID_ARG, "device ordinal out of range");
+  HIPCHECK(hipSetDevice(device));
+  revo_ctx* c = new revo_ctx();
+  c->device = device;
+  c->ps = *pyr;
+  if (opt) c->os = *opt; else revo_opt_settings_default(&c->os);
+  if (trk) c->ts = *trk; else revo_tracker_settings_default(&c->ts);
+  std::string why;
+  if (build_geom(c->ps, &c->geom, &why)) { delete c; return fail(REVO_ERR_INVALID_ARG, why); }
+  build_track_params(c, &c->tp);
+  HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
+  HIPCHECK(hipMalloc((void**)&c->d_desc, sizeof(PairDesc)));
+  HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result)));
+  HIPCHECK(hipMalloc((void**)&c->d_res, sizeof(revo_pair_result)));
+  HIPCHECK(hipHostMalloc((void**)&c->h_eval, sizeof(EvalOut)));
+  HIPCHECK(hipMalloc((void**)&c->d_eval, sizeof(EvalOut)));
+  size_t maxpix = 0;
+  for (int l = 0; l < c->geom.n_levels; ++l) maxpix = std::max(maxpix, (size_t)c->geom.lv[l].npix);
+  HIPCHECK(hipMalloc((void**)&c->d_marks, sizeof(int) * maxpix));
+  HIPCHECK(hipMalloc((void**)&c->d_hist8, sizeof(int) * 8));
+  HIPCHECK(hipHostMalloc((void**)&c->h_hist8, sizeof(int) * 8));
+  HIPCHECK(hipMalloc((void**)&c->d_cloud_pts, sizeof(void*) * 4));
+  HIPCHECK(hipMalloc((void**)&c->d_cloud_n, sizeof(void*) * 4));
+  HIPCHECK(hipMalloc((void**)&c->d_RT, sizeof(float) * 12 * 4));
+  HIPCHECK(hipHostMalloc((void**)&c->h_cloud_pts, sizeof(void*) * 4));
+  HIPCHECK(hipHostMalloc((void**)&c->h_cloud_n, sizeof(void*) * 4));
+  HIPCHECK(hipHostMalloc((void**)&c->h_RT, sizeof(float) * 12 * 4));
+  *out = c;
+  return REVO_OK;
+}
+
+extern "C" void revo_ctx_destroy(revo_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& p : c->past) { hipFree(p.d_pts); hipFree(p.d_n); }
+  for (FrameSet* fs : c->pool) frameset_destroy(fs);
+  hipHostFree(c->h_desc); hipFree(c->d_desc); hipHostFree(c->h_res); hipFree(c->d_res);
+  hipHostFree(c->h_eval); hipFree(c->d_eval);
+  hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8);
+  hipFree(c->d_cloud_pts); hipFree(c->d_cloud_n); hipFree(c->d_RT);
+  hipHostFree(c->h_cloud_pts); hipHostFree(c->h_cloud_n); hipHostFree(c->h_RT);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int revo_ctx_set_tracker(revo_ctx* c, const revo_opt_settings* opt, const revo_tracker_settings* trk) {
+  if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (opt) c->os = *opt;
+  if (trk) c->ts = *trk;
+  build_track_params(c, &c->tp);
+  return REVO_OK;
+}
+
+extern "C" int revo_ctx_camera(const revo_ctx* c, int lvl, float out6[6]) {
+  if (!c || !out6) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
+  const LevelGeom& v = c->geom.lv[lvl];
+  out6[0] = v.fx; out6[1] = v.fy; out6[2] = v.cx; out6[3] = v.cy; out6[4] = (float)v.w; out6[5] = (float)v.h;
+  return REVO_OK;
+}
+
+// ----------------------------------------------------------------- pyramids --
+static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_stride, const void* depth,
+                                 size_t depth_stride, bool is_u16, double scale, double ts, revo_pyr** out) {
+  if (!c || !bgr || !depth || !out) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(c->device));
+  const int w = c->geom.lv[0].w, h = c->geom.lv[0].h;
+  if (bgr_stride < (size_t)w * 3 || depth_stride < (size_t)w * (is_u16 ? 2 : 4))
+    return fail(REVO_ERR_INVALID_ARG, "stride smaller than a row");
+  FrameSet* fs = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->pool.empty()) { fs = c->pool.back(); c->pool.pop_back(); }
+  }
+  if (!fs) {
+    int rc = frameset_create(c, 1, true, &fs);
+    if (rc) return rc;
+  }
+  // The reference clones its inputs (imgpyramidrgbd.cpp:51,54): the copies below are
+  // complete (w.r.t. the caller's buffers) when these calls return.
+  HIPCHECK(hipMemcpy2DAsync(fs->d_bgr, (size_t)w * 3, bgr, bgr_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
+  const size_t drow = (size_t)w * (is_u16 ? 2 : 4);
+  HIPCHECK(hipMemcpy2DAsync(fs->d_depth, drow, depth, depth_stride, drow, h, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));  // pageable sources: make the clone guarantee explicit
+  const float alpha = is_u16 ? (float)(1.0f / scale) : 0.0f;  // iowrapperRGBD.cpp:327
+  enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha,
+                c->stream);
+  HIPCHECK(hipGetLastError());
+  revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts};
+  *out = p;
+  return REVO_OK;
+}
+
+extern "C" int revo_pyramid_create(revo_ctx* ctx, const uint8_t* bgr, size_t bgr_stride, const float* depth_m,
+                                   size_t depth_stride, double timestamp, revo_pyr** out) {
+  return pyramid_create_common(ctx, bgr, bgr_stride, depth_m, depth_stride, false, 1.0, timestamp, out);
+}
+extern "C" int revo_pyramid_create_u16(revo_ctx* ctx, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth_raw,
+                                       size_t depth_stride, double depth_scale_factor, double timestamp, revo_pyr** out) {
+  if (!(depth_scale_factor > 0)) return fail(REVO_ERR_INVALID_ARG, "depth_scale_factor must be > 0");
+  return pyramid_create_common(ctx, bgr, bgr_stride, depth_raw, depth_stride, true, depth_scale_factor, timestamp, out);
+}
+
+extern "C" void revo_pyramid_destroy(revo_pyr* p) {
+  if (!p) return;
+  if (p->owns_fs) {
+    // stream-ordered reuse: later work on the same stream runs after everything that reads this set
+    std::lock_guard<std::mutex> lk(p->ctx->mu);
+    p->ctx->pool.push_back(p->fs);
+  }
+  delete p;
+}
+
+extern "C" int revo_pyramid_make_keyframe(revo_pyr* p) {
+  if (!p) return fail(REVO_ERR_INVALID_ARG, "null pyramid");
+  HIPCHECK(hipSetDevice(p->ctx->device));
+  launch_keyframe(p->ctx->geom, p->fs->p, p->frame, 1, 1, p->ctx->stream);
+  HIPCHECK(hipGetLastError());
+  p->is_kf = true;
+  return REVO_OK;
+}
+extern "C" int revo_pyramid_is_keyframe(const revo_pyr* p) { return p && p->is_kf; }
+extern "C" double revo_pyramid_timestamp(const revo_pyr* p) { return p ? p->ts : 0.0; }
+
+extern "C" int revo_pyramid_read(revo_pyr* p, revo_plane what, int lvl, void* dst, size_t cap, size_t* count) {
+  if (!p) return fail(REVO_ERR_INVALID_ARG, "null pyramid");
+  revo_ctx* c = p->ctx;
+  HIPCHECK(hipSetDevice(c->device));
+  if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
+  const LevelGeom& v = c->geom.lv[lvl];
+  const FramePlanes& P = p->fs->p;
+  const size_t f = (size_t)p->frame;
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  const void* src = nullptr;
+  size_t n = v.npix, esz = 1;
+  switch (what) {
+    case REVO_PLANE_GRAY: src = P.gray[lvl] + f * v.npix; break;
+    case REVO_PLANE_DEPTH: src = P.depth[lvl] + f * v.npix; esz = 4; break;
+    case REVO_PLANE_EDGES: src = P.edges[lvl] + f * v.npix; break;
+    case REVO_PLANE_EDGES_ORIG:  // returnOrigEdges, imgpyramidrgbd.h:67-75
+      src = ((c->ps.use_edge_hist && lvl > c->ps.pyr_max_lvl) ? P.edges_orig[lvl] : P.edges[lvl]) + f * v.npix;
+      break;
+    case REVO_PLANE_DT:
+      if (!p->is_kf) return fail(REVO_ERR_NOT_KEYFRAME, "distance transform not built: call makeKeyframe");
+      src = P.dt[lvl] + f * v.npix; esz = 4; break;
+    case REVO_PLANE_GRADTABLE:
+      if (!p->is_kf) return fail(REVO_ERR_NOT_KEYFRAME, "optimizationStructure not built");
+      src = P.table[lvl] + f * v.npix; esz = 16; break;
+    case REVO_PLANE_EDGES3D: {
+      int np = 0;
+      HIPCHECK(hipMemcpy(&np, P.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToHost));
+      n = (size_t)np; src = P.pts[lvl] + f * v.npix; esz = 16; break;
+    }
+    case REVO_PLANE_HIST:
+      if (v.patch <= 0) { n = 0; src = P.hist[lvl]; break; }
+      n = (size_t)v.hist_w * v.hist_h; src = P.hist[lvl] + f * n; break;
+    default: return fail(REVO_ERR_INVALID_ARG, "unknown plane");
+  }
+  if (count) *count = n;
+  if (dst) {
+    if (n * esz > cap) return fail(REVO_ERR_CAPACITY, "host buffer too small");
+    if (n) HIPCHECK(hipMemcpy(dst, src, n * esz, hipMemcpyDeviceToHost));
+  }
+  return REVO_OK;
+}
+
+// ------------------------------------------------------------------ tracking --
+static void fill_desc(PairDesc* d, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T) {
+  const PyrGeom& g = ref->ctx->geom;
+  memset(d, 0, sizeof(*d));
+  for (int l = 0; l < g.n_levels; ++l) {
+    d->pts[l] = curr->fs->p.pts[l] + (size_t)curr->frame * g.lv[l].npix;
+    d->table[l] = ref->fs->p.table[l] + (size_t)ref->frame * g.lv[l].npix;
+  }
+  d->npts = curr->fs->p.npts + (size_t)curr->frame * REVO_L;
+  const int cl = ref->ctx->ps.pyr_min_lvl;
+  d->dt_coarse = ref->fs->p.dt[cl] + (size_t)ref->frame * g.lv[cl].npix;
+  if (R) memcpy(d->R, R, sizeof(float) * 9); else { d->R[0] = d->R[4] = d->R[8] = 1.f; }
+  if (T) memcpy(d->T, T, sizeof(float) * 3);
+}
+
+static int check_pair(const revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr) {
+  if (!c || !ref || !curr) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (ref->ctx != c || curr->ctx != c) return fail(REVO_ERR_INVALID_ARG, "pyramid belongs to another context");
+  if (!ref->is_kf) return fail(REVO_ERR_NOT_KEYFRAME, "optimizationStructure not built! (reference frame is not a keyframe)");
+  return REVO_OK;
+}
+
+static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
+                      const TrackParams& tp) {
+  fill_desc(c->h_desc, ref, curr, R, T);
+  HIPCHECK(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PairDesc), hipMemcpyHostToDevice, c->stream));
+  launch_track(c->d_desc, tp, c->d_res, c->d_eval, 1, c->stream);
+  HIPCHECK(hipGetLastError());
+  if (tp.eval_only) HIPCHECK(hipMemcpyAsync(c->h_eval, c->d_eval, sizeof(EvalOut), hipMemcpyDeviceToHost, c->stream));
+  else HIPCHECK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(revo_pair_result), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return REVO_OK;
+}
+
+extern "C" int revo_optimizer_track_level(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, float R[9], float T[3],
+                                          int lvl, revo_residual_info* info, float* err) {
+  int rc = check_pair(c, ref, curr);
+  if (rc) return rc;
+  if (!R || !T) return fail(REVO_ERR_INVALID_ARG, "null pose");
+  if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  TrackParams tp = c->tp;
+  tp.lvl_begin = tp.lvl_end = lvl; tp.check_init = 0; tp.eval_only = 0;
+  rc = run_single(c, ref, curr, R, T, tp);
+  if (rc) return rc;
+  const revo_pair_result& r = *c->h_res;
+  if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
+  memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
+  if (err) *err = r.err;
+  if (info) { info->good_pts_edges = r.good; info->bad_pts_edges = r.bad; info->sum_error_unweighted = 0.f; info->sum_error_weighted = 0.f; }
+  return REVO_OK;
+}
+
+extern "C" int revo_optimizer_eval(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float R[9],
+                                   const float T[3], int lvl, revo_residual_info* info, float* err, float A[36],
+                                   float b[6]) {
+  int rc = check_pair(c, ref, curr);
+  if (rc) return rc;
+  if (!R || !T) return fail(REVO_ERR_INVALID_ARG, "null pose");
+  if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  TrackParams tp = c->tp;
+  tp.lvl_begin = tp.lvl_end = lvl; tp.check_init = 0; tp.eval_only = 1;
+  rc = run_single(c, ref, curr, R, T, tp);
+  if (rc) return rc;
+  const EvalOut& e = *c->h_eval;
+  if (info) { info->good_pts_edges = e.good; info->bad_pts_edges = e.bad; info->sum_error_unweighted = e.sum_u; info->sum_error_weighted = e.sum_w; }
+  if (err) *err = e.mean_err;
+  if (A) memcpy(A, e.A, sizeof(float) * 36);
+  if (b) memcpy(b, e.b, sizeof(float) * 6);
+  return REVO_OK;
+}
+
+extern "C" int revo_tracker_track_frames(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, float R[9], float T[3],
+                                         float* err, int* status, revo_residual_info* info, int32_t iters[REVO_MAX_LEVELS]) {
+  int rc = check_pair(c, ref, curr);
+  if (rc) return rc;
+  if (!R || !T) return fail(REVO_ERR_INVALID_ARG, "null pose");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  TrackParams tp = c->tp;
+  tp.eval_only = 0;
+  rc = run_single(c, ref, curr, R, T, tp);
+  if (rc) return rc;
+  const revo_pair_result& r = *c->h_res;
+  if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
+  memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
+  if (err) *err = r.err;
+  if (status) *status = r.status;
+  if (info) { info->good_pts_edges = r.good; info->bad_pts_edges = r.bad; info->sum_error_unweighted = 0.f; info->sum_error_weighted = 0.f; }
+  if (iters) memcpy(iters, r.evals, sizeof(int32_t) * REVO_L);
+  return REVO_OK;
+}
+
+// ---- 4x4 helpers (column-major), Eigen Matrix4f::inverse() semantics (tracker.cpp:142)
+static void mat4_inverse(const float* m, float* inv) {
+  float o[16];
+  o[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  o[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  o[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  o[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  o[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  o[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  o[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  o[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  o[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  o[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  o[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  o[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  o[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  o[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  o[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  o[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const float det = m[0] * o[0] + m[1] * o[4] + m[2] * o[8] + m[3] * o[12];
+  const float idet = 1.0f / det;
+  for (int i = 0; i < 16; ++i) inv[i] = o[i] * idet;
+}
+static void mat4_mul(const float* A, const float* B, float* out) {
+  float o[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      o[c * 4 + r] = A[0 * 4 + r] * B[c * 4 + 0] + A[1 * 4 + r] * B[c * 4 + 1] + A[2 * 4 + r] * B[c * 4 + 2] + A[3 * 4 + r] * B[c * 4 + 3];
+  memcpy(out, o, sizeof(o));
+}
+
+extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* status,
+                                           int32_t hist4[4], int32_t overlaps4[4]) {
+  if (!c || !T_w_curr || !curr) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (curr->ctx != c) return fail(REVO_ERR_INVALID_ARG, "pyramid belongs to another context");
+  if (hist4) memset(hist4, 0, sizeof(int32_t) * 4);
+  if (overlaps4) memset(overlaps4, 0, sizeof(int32_t) * 4);
+  if (status) *status = REVO_TRACKER_STATE_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->past.empty() || !c->ts.check_tracking_results) return REVO_OK;  // tracker.cpp:121
+  const int hl = c->ts.histogram_level;
+  if (hl < 0 || hl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "histogram_level outside the pyramid");
+  HIPCHECK(hipSetDevice(c->device));
+  float inv[16];
+  mat4_inverse(T_w_curr, inv);
+  int nframes = 0;
+  for (int fr = 0; fr < c->ts.n_frames_hist_voting && fr < (int)c->past.size() && fr < 3; ++fr) {
+    float tf[16];
+    mat4_mul(inv, c->past[fr].T_w, tf);
+    float* RT = c->h_RT + 12 * fr;
+    for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 3; ++r) RT[cc * 3 + r] = tf[cc * 4 + r];
+    RT[9] = tf[12]; RT[10] = tf[13]; RT[11] = tf[14];
+    c->h_cloud_pts[fr] = c->past[fr].d_pts;
+    c->h_cloud_n[fr] = c->past[fr].d_n;
+    ++nframes;
+  }
+  HIPCHECK(hipMemcpyAsync(c->d_RT, c->h_RT, sizeof(float) * 12 * nframes, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(c->d_cloud_pts, c->h_cloud_pts, sizeof(void*) * nframes, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(c->d_cloud_n, c->h_cloud_n, sizeof(void*) * nframes, hipMemcpyHostToDevice, c->stream));
+  const int use_orig = (c->ps.use_edge_hist && hl > c->ps.pyr_max_lvl) ? 1 : 0;
+  launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, c->d_cloud_pts, c->d_cloud_n, c->d_RT, c->d_marks, c->d_hist8,
+              use_orig, c->stream);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(c->h_hist8, c->d_hist8, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  const int* hist = c->h_hist8;
+  const int* ov = c->h_hist8 + 4;
+  const float wts[4] = {0.f, 1.f, 1.25f, 1.5f};  // tracker.cpp:231-234
+  float overlapMeasure = 0.0f;
+  const int hsize = 1 + nframes;
+  for (int k = 1; k < hsize; ++k) overlapMeasure += (ov[k] * wts[k]);
+  if (hist4) memcpy(hist4, hist, sizeof(int32_t) * 4);
+  if (overlaps4) memcpy(overlaps4, ov, sizeof(int32_t) * 4);
+  if (status) *status = (overlapMeasure >= ov[0] || hsize < 4) ? REVO_TRACKER_STATE_OK : REVO_TRACKER_STATE_NEW_KF;  // tracker.cpp:184
+  return REVO_OK;
+}
+
+extern "C" int revo_tracker_add_old_pcl(revo_ctx* c, const revo_pyr* src, int lvl, const float T_w[16], double ts) {
+  if (!c || !src || !T_w) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  // the reference copies the Eigen matrix (tracker.cpp:219); the copy stays in HBM
+  Past p{};
+  const size_t f = (size_t)src->frame;
+  HIPCHECK(hipMemcpyAsync(c->h_hist8, src->fs->p.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  p.n = c->h_hist8[0];
+  HIPCHECK(hipMalloc((void**)&p.d_pts, sizeof(float4) * (size_t)std::max(1, p.n)));
+  HIPCHECK(hipMalloc((void**)&p.d_n, sizeof(int)));
+  HIPCHECK(hipMemcpyAsync(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, sizeof(float4) * (size_t)p.n,
+                          hipMemcpyDeviceToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(p.d_n, src->fs->p.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  memcpy(p.T_w, T_w, sizeof(float) * 16);
+  p.ts = ts;
+  c->past.push_back(p);
+  return REVO_OK;
+}
+
+extern "C" int revo_tracker_clear_past(revo_ctx* c) {  // tracker.cpp:248-257
+  if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  while ((int)c->past.size() > c->ts.n_frames_hist_voting) {
+    hipFree(c->past.front().d_pts); hipFree(c->past.front().d_n);
+    c->past.pop_front();
+  }
+  return REVO_OK;
+}
+extern "C" int revo_tracker_past_size(const revo_ctx* c) { return c ? (int)c->past.size() : 0; }
+
+// -------------------------------------------------------------------- batch --
+extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
+  if (!c || !out || n_pairs <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
+  HIPCHECK(hipSetDevice(c->device));
+  revo_batch* b = new revo_batch();
+  b->ctx = c; b->n_pairs = n_pairs;
+  int rc = frameset_create(c, 2 * n_pairs, false, &b->fs);
+  if (rc) { delete b; return rc; }
+  HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
+  for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0});
+  HIPCHECK(hipHostMalloc((void**)&b->h_descs, sizeof(PairDesc) * n_pairs));
+  HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
+  for (int i = 0; i < n_pairs; ++i) fill_desc(&b->h_descs[i], &b->views[2 * i], &b->views[2 * i + 1], nullptr, nullptr);
+  HIPCHECK(hipStreamSynchronize(c->stream));  // frameset_create's memset
+  *out = b;
+  return REVO_OK;
+}
+extern "C" void revo_batch_destroy(revo_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->stream);
+  hipHostFree(b->h_descs); hipFree(b->d_descs);
+  hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+  hipStreamDestroy(b->stream);
+  frameset_destroy(b->fs);
+  delete b;
+}
+
+extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream) {
+  if (!b || !d_bgr || !d_depth) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(b->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s);
+  launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
+  HIPCHECK(hipGetLastError());
+  return REVO_OK;
+}
+
+static int batch_upload_init(revo_batch* b, const float* h_init_RT, hipStream_t s) {
+  for (int i = 0; i < b->n_pairs; ++i) {
+    PairDesc& d = b->h_descs[i];
+    if (h_init_RT) { memcpy(d.R, h_init_RT + 12 * i, sizeof(float) * 9); memcpy(d.T, h_init_RT + 12 * i + 9, sizeof(float) * 3); }
+    else { memset(d.R, 0, sizeof(d.R)); d.R[0] = d.R[4] = d.R[8] = 1.f; memset(d.T, 0, sizeof(d.T)); }
+  }
+  HIPCHECK(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, s));
+  return REVO_OK;
+}
+
+extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo_pair_result* d_results, void* stream) {
+  if (!b || !d_results) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(b->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  int rc = batch_upload_init(b, h_init_RT, s);
+  if (rc) return rc;
+  TrackParams tp = b->ctx->tp;
+  tp.eval_only = 0;
+  launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, s);
+  HIPCHECK(hipGetLastError());
+  return REVO_OK;
+}
+
+extern "C" int revo_batch_track(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, const float* h_init_RT,
+                                revo_pair_result* d_results, void* stream) {
+  int rc = revo_batch_build(b, d_bgr, d_depth, stream);
+  if (rc) return rc;
+  return revo_batch_track_only(b, h_init_RT, d_results, stream);
+}
+
+extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
+  if (!b) return fail(REVO_ERR_INVALID_ARG, "null batch");
+  HIPCHECK(hipSetDevice(b->ctx->device));
+  HIPCHECK(hipStreamSynchronize(stream ? (hipStream_t)stream : b->stream));
+  return REVO_OK;
+}
+
+extern "C" int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out) {
+  if (!b || !out || frame < 0 || frame >= 2 * b->n_pairs) return fail(REVO_ERR_INVALID_ARG, "bad frame index");
+  *out = &b->views[frame];
+  return REVO_OK;
+}
+
+extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, revo_pair_result* d_results, void* stream,
+                                       int reps, float* ms_mean) {
+  if (!b || !d_results || !ms_mean || reps <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
+  HIPCHECK(hipSetDevice(b->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  int rc = batch_upload_init(b, h_init_RT, s);
+  if (rc) return rc;
+  TrackParams tp = b->ctx->tp;
+  tp.eval_only = 0;
+  float total = 0.f;
+  for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
+    HIPCHECK(hipEventRecord(b->ev0, s));
+    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, s);
+    HIPCHECK(hipEventRecord(b->ev1, s));
+    HIPCHECK(hipEventSynchronize(b->ev1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    total += ms;
+  }
+  *ms_mean = total / (float)reps;
+  return REVO_OK;
+}

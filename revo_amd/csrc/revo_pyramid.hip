@@ -1,0 +1,625 @@
+// revo_pyramid.hip -- gfx950 kernels for the per-frame pyramid build
+// (ImgPyramidRGBD ctor, imgpyramidrgbd.cpp:43-96,173-229) and the keyframe
+// promotion (makeKeyframe, imgpyramidrgbd.cpp:231-276).
+//
+// All stages are HBM-bound integer/byte streaming or small stencils: coalesced
+// dword/dwordx4 row accesses, LDS tiles for the 5x5 / 3x3 stencils and the
+// union-find hysteresis, blockIdx.z = frame, blockIdx.x decodes level + tile so
+// one launch covers every level of every frame in the batch.  No MFMA: there
+// is no contraction anywhere on this path.
+//
+// Exactness: every integer stage is bit-exact by construction; float stages
+// keep the reference's operation order and are compiled with -ffp-contract=off.
+#include "revo_dev.h"
+
+namespace {
+
+__device__ __forceinline__ int level_of(const PyrGeom& g, int v, int LevelGeom::*base) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < REVO_L; ++k)
+    if (k < g.n_levels && v >= g.lv[k].*base) l = k;
+  return l;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+// ---------------------------------------------------------------------------
+// a2: cv::cvtColor BGR->GRAY (imgpyramidrgbd.cpp:53) fused with the depth clone
+// (cpp:54) or the u16 -> metres conversion of iowrapperRGBD.cpp:326-327.
+// 4 pixels per thread: 3 dword loads of BGR, 1 dword store of gray, float4 depth.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ bgr, const float* __restrict__ depth_f32,
+                                                    const uint16_t* __restrict__ depth_u16, float alpha,
+                                                    uint8_t* __restrict__ gray, float* __restrict__ depth_out, int npix) {
+  const int f = blockIdx.z;
+  const int g4 = blockIdx.x * 256 + threadIdx.x;
+  if (g4 * 4 >= npix) return;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(bgr + (size_t)f * npix * 3) + (size_t)g4 * 3;
+  const uint32_t a = src[0], b = src[1], c = src[2];
+  // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3
+  const int B0 = a & 255, G0 = (a >> 8) & 255, R0 = (a >> 16) & 255, B1 = a >> 24;
+  const int G1 = b & 255, R1 = (b >> 8) & 255, B2 = (b >> 16) & 255, G2 = b >> 24;
+  const int R2 = c & 255, B3 = (c >> 8) & 255, G3 = (c >> 16) & 255, R3 = c >> 24;
+  const uint32_t y0 = (uint32_t)(B0 * 1868 + G0 * 9617 + R0 * 4899 + 8192) >> 14;
+  const uint32_t y1 = (uint32_t)(B1 * 1868 + G1 * 9617 + R1 * 4899 + 8192) >> 14;
+  const uint32_t y2 = (uint32_t)(B2 * 1868 + G2 * 9617 + R2 * 4899 + 8192) >> 14;
+  const uint32_t y3 = (uint32_t)(B3 * 1868 + G3 * 9617 + R3 * 4899 + 8192) >> 14;
+  reinterpret_cast<uint32_t*>(gray + (size_t)f * npix)[g4] = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+  float4 d;
+  if (depth_u16) {
+    const uint2 r = reinterpret_cast<const uint2*>(depth_u16 + (size_t)f * npix)[g4];
+    d.x = (float)(r.x & 0xffff) * alpha + 0.0f;
+    d.y = (float)(r.x >> 16) * alpha + 0.0f;
+    d.z = (float)(r.y & 0xffff) * alpha + 0.0f;
+    d.w = (float)(r.y >> 16) * alpha + 0.0f;
+  } else {
+    d = reinterpret_cast<const float4*>(depth_f32 + (size_t)f * npix)[g4];
+  }
+  reinterpret_cast<float4*>(depth_out + (size_t)f * npix)[g4] = d;
+}
+
+// ---------------------------------------------------------------------------
+// a3 + a4: cv::pyrDown (imgpyramidrgbd.cpp:82) + FilterSubsampleWithHoles
+// (imgpyramidrgbd.h:218-249).  32x8 output tile per 256-thread block; the
+// (2*32+3)x(2*8+3) u8 source tile is staged in LDS, separable [1 4 6 4 1].
+// ---------------------------------------------------------------------------
+#define PD_TW 32
+#define PD_TH 8
+__global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
+                                                 int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst) {
+  __shared__ uint8_t s_src[2 * PD_TH + 3][2 * PD_TW + 3 + 1];
+  __shared__ int s_h[2 * PD_TH + 3][PD_TW + 1];
+  const int f = blockIdx.z;
+  src += (size_t)f * sw * sh;
+  dst += (size_t)f * dw * dh;
+  dsrc += (size_t)f * sw * sh;
+  ddst += (size_t)f * dw * dh;
+  const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (2 * PD_TH + 3) * (2 * PD_TW + 3); i += 256) {
+    const int r = i / (2 * PD_TW + 3), c = i % (2 * PD_TW + 3);
+    const int sy = reflect101(2 * oy0 - 2 + r, sh), sx = reflect101(2 * ox0 - 2 + c, sw);
+    s_src[r][c] = src[(size_t)sy * sw + sx];
+  }
+  __syncthreads();
+  for (int i = tid; i < (2 * PD_TH + 3) * PD_TW; i += 256) {
+    const int r = i / PD_TW, c = i % PD_TW;
+    const uint8_t* p = &s_src[r][2 * c];
+    s_h[r][c] = p[0] + p[4] + 4 * (p[1] + p[3]) + 6 * p[2];
+  }
+  __syncthreads();
+  const int lx = tid % PD_TW, ly = tid / PD_TW;
+  const int ox = ox0 + lx, oy = oy0 + ly;
+  if (ox < dw && oy < dh) {
+    const int v = s_h[2 * ly][lx] + s_h[2 * ly + 4][lx] + 4 * (s_h[2 * ly + 1][lx] + s_h[2 * ly + 3][lx]) + 6 * s_h[2 * ly + 2][lx];
+    dst[(size_t)oy * dw + ox] = (uint8_t)((v + 128) >> 8);
+    // depth: mean of the positive samples of the 2x2 block, reference order
+    const float2 r0 = *reinterpret_cast<const float2*>(dsrc + (size_t)(2 * oy) * sw + 2 * ox);
+    const float2 r1 = *reinterpret_cast<const float2*>(dsrc + (size_t)(2 * oy + 1) * sw + 2 * ox);
+    float out = 0.0f, cnt = 0.0f;
+    if (r0.x > 0.0f) { out += r0.x; cnt += 1.0f; }
+    if (r0.y > 0.0f) { out += r0.y; cnt += 1.0f; }
+    if (r1.x > 0.0f) { out += r1.x; cnt += 1.0f; }
+    if (r1.y > 0.0f) { out += r1.y; cnt += 1.0f; }
+    if (cnt > 0.0f) out = __fdiv_rn(out, cnt);
+    ddst[(size_t)oy * dw + ox] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Union-find helpers for the Canny hysteresis.  Keys are pixel indices; the
+// parent of a pixel always has a smaller key, roots point to themselves.
+// Lock-free union by atomicMin (Komura-style); placement/order independent.
+// ---------------------------------------------------------------------------
+template <typename P>
+__device__ __forceinline__ int uf_load(P* L, int i) { return __atomic_load_n(&L[i], __ATOMIC_RELAXED); }
+
+template <typename P>
+__device__ __forceinline__ int uf_find(P* L, int x) {
+  int p = uf_load(L, x);
+  while (p != x) { x = p; p = uf_load(L, x); }
+  return x;
+}
+template <typename P>
+__device__ __forceinline__ void uf_unite(P* L, int a, int b) {
+  for (;;) {
+    a = uf_find(L, a);
+    b = uf_find(L, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }  // a < b: hang b under a
+    const int old = atomicMin(&L[b], a);
+    if (old == b) return;
+    b = old;  // b was re-parented meanwhile: keep that link by uniting with it too
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a5 (first half): cv::Canny's Sobel 3x3 (BORDER_REPLICATE) + L2 magnitude +
+// non-maximum suppression (imgpyramidrgbd.cpp:184), 64x16 tile + halo in LDS.
+// Writes the map {0 none, 1 weak, 2 strong} and, per tile, resolves the
+// 8-connectivity of the candidates with a union-find in LDS; the global parent
+// array gets each pixel's tile-local root (as a global pixel index).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
+  __shared__ uint8_t s_g[NMS_TILE_H + 4][NMS_TILE_W + 4 + 4];
+  __shared__ int s_mag[NMS_TILE_H + 2][NMS_TILE_W + 2 + 1];
+  __shared__ int s_dxy[NMS_TILE_H + 2][NMS_TILE_W + 2 + 1];
+  __shared__ int s_lab[NMS_TILE_H * NMS_TILE_W];
+  const int f = blockIdx.z;
+  const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
+  const LevelGeom lv = g.lv[l];
+  const int t = blockIdx.x - lv.tile_base;
+  const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
+  const int w = lv.w, h = lv.h;
+  const uint8_t* gray = pl.gray[l] + (size_t)f * lv.npix;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < (NMS_TILE_H + 4) * (NMS_TILE_W + 4); i += 256) {
+    const int r = i / (NMS_TILE_W + 4), c = i % (NMS_TILE_W + 4);
+    const int gy = clampi(y0 - 2 + r, 0, h - 1), gx = clampi(x0 - 2 + c, 0, w - 1);
+    s_g[r][c] = gray[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+  for (int i = tid; i < (NMS_TILE_H + 2) * (NMS_TILE_W + 2); i += 256) {
+    const int r = i / (NMS_TILE_W + 2), c = i % (NMS_TILE_W + 2);
+    const int ix = x0 - 1 + c, iy = y0 - 1 + r;
+    int mag = 0, dxy = 0;
+    if (ix >= 0 && ix < w && iy >= 0 && iy < h) {
+      const int a = s_g[r][c], b = s_g[r][c + 1], cc = s_g[r][c + 2];
+      const int d = s_g[r + 1][c], e = s_g[r + 1][c + 2];
+      const int p = s_g[r + 2][c], q = s_g[r + 2][c + 1], rr = s_g[r + 2][c + 2];
+      const int dx = (cc + 2 * e + rr) - (a + 2 * d + p);
+      const int dy = (p + 2 * q + rr) - (a + 2 * b + cc);
+      mag = dx * dx + dy * dy;
+      dxy = (int)(((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16));
+    }
+    s_mag[r][c] = mag;
+    s_dxy[r][c] = dxy;
+  }
+  __syncthreads();
+
+  const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
+  const int lx0 = (tid % 16) * 4, ly = tid / 16;
+  uint32_t packed = 0;
+  int cand[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int lx = lx0 + k;
+    const int m = s_mag[ly + 1][lx + 1];
+    int val = 0;
+    if (m > g.canny_low) {
+      const int dxy = s_dxy[ly + 1][lx + 1];
+      const int xs = (int)(int16_t)(dxy & 0xffff), ys = dxy >> 16;
+      const int ax = abs(xs), ay = abs(ys) << 15;
+      const int tg22x = ax * TG22;
+      bool is_max;
+      if (ay < tg22x) {
+        is_max = m > s_mag[ly + 1][lx] && m >= s_mag[ly + 1][lx + 2];
+      } else {
+        const int tg67x = tg22x + (ax << 16);
+        if (ay > tg67x) {
+          is_max = m > s_mag[ly][lx + 1] && m >= s_mag[ly + 2][lx + 1];
+        } else {
+          const int s = (xs ^ ys) < 0 ? -1 : 1;
+          is_max = m > s_mag[ly][lx + 1 - s] && m > s_mag[ly + 2][lx + 1 + s];
+        }
+      }
+      if (is_max) val = (m > g.canny_high) ? 2 : 1;
+    }
+    const bool inside = (x0 + lx < w) && (y0 + ly < h);
+    if (!inside) val = 0;
+    cand[k] = val;
+    packed |= (uint32_t)val << (8 * k);
+    s_lab[ly * NMS_TILE_W + lx] = val ? ly * NMS_TILE_W + lx : -1;
+  }
+  __syncthreads();
+  // tile-local 8-connectivity: unite with W, NW, N, NE inside the tile
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!cand[k]) continue;
+    const int lx = lx0 + k;
+    const int me = ly * NMS_TILE_W + lx;
+    if (lx > 0 && s_lab[me - 1] >= 0) uf_unite(s_lab, me, me - 1);
+    if (ly > 0) {
+      if (lx > 0 && s_lab[me - NMS_TILE_W - 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W - 1);
+      if (s_lab[me - NMS_TILE_W] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W);
+      if (lx < NMS_TILE_W - 1 && s_lab[me - NMS_TILE_W + 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W + 1);
+    }
+  }
+  __syncthreads();
+  if (x0 + lx0 < w && y0 + ly < h) {
+    const size_t pix = (size_t)(y0 + ly) * w + x0 + lx0;
+    *reinterpret_cast<uint32_t*>(pl.nms[l] + (size_t)f * lv.npix + pix) = packed;
+    int4 lab;
+    int* lp = &lab.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int key = -1;
+      if (cand[k]) {
+        const int r = uf_find(s_lab, ly * NMS_TILE_W + lx0 + k);
+        key = (y0 + r / NMS_TILE_W) * w + x0 + (r % NMS_TILE_W);
+      }
+      lp[k] = key;
+    }
+    *reinterpret_cast<int4*>(pl.scratch[l] + (size_t)f * lv.npix + pix) = lab;
+  }
+}
+
+// a5 (second half, 1/3): unite candidates across tile borders (global memory).
+__global__ void __launch_bounds__(256) k_ccl_border(PyrGeom g, FramePlanes pl) {
+  const int f = blockIdx.z;
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  if (gi >= g.total_pix) return;
+  const int l = level_of(g, gi, &LevelGeom::pix_base);
+  const LevelGeom lv = g.lv[l];
+  const int p = gi - lv.pix_base;
+  const int w = lv.w;
+  const int x = p % w, y = p / w;
+  const int lx = x % NMS_TILE_W, lyy = y % NMS_TILE_H;
+  if (lx != 0 && lyy != 0 && lx != NMS_TILE_W - 1) return;
+  int* L = pl.scratch[l] + (size_t)f * lv.npix;
+  if (L[p] < 0) return;
+  // neighbours that live in another tile
+  if (lx == 0 && x > 0 && L[p - 1] >= 0) uf_unite(L, p, p - 1);
+  if (y > 0) {
+    if ((lx == 0 || lyy == 0) && x > 0 && L[p - w - 1] >= 0) uf_unite(L, p, p - w - 1);
+    if (lyy == 0 && L[p - w] >= 0) uf_unite(L, p, p - w);
+    if ((lx == NMS_TILE_W - 1 || lyy == 0) && x < w - 1 && L[p - w + 1] >= 0) uf_unite(L, p, p - w + 1);
+  }
+}
+
+// a5 (2/3): every strong pixel marks the root of its component (bit 2 of the map).
+__global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
+  const int f = blockIdx.z;
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  if (gi >= g.total_pix) return;
+  const int l = level_of(g, gi, &LevelGeom::pix_base);
+  const LevelGeom lv = g.lv[l];
+  const int p = gi - lv.pix_base;
+  uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
+  if ((nms[p] & 3) != 2) return;
+  int* L = pl.scratch[l] + (size_t)f * lv.npix;
+  const int r = uf_find(L, p);
+  nms[r] = (uint8_t)((nms[r] & 3) | 4);  // all writers store the same value
+}
+
+// a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes
+// edgesPyr and its clone edgesOrigPyr (imgpyramidrgbd.cpp:185-186).
+__global__ void __launch_bounds__(256) k_ccl_out(PyrGeom g, FramePlanes pl) {
+  const int f = blockIdx.z;
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  if (gi >= g.total_pix) return;
+  const int l = level_of(g, gi, &LevelGeom::pix_base);
+  const LevelGeom lv = g.lv[l];
+  const int p = gi - lv.pix_base;
+  const uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
+  uint8_t e = 0;
+  if (nms[p] & 3) {
+    int* L = pl.scratch[l] + (size_t)f * lv.npix;
+    const int r = uf_find(L, p);
+    e = (nms[r] & 4) ? 255 : 0;
+  }
+  pl.edges[l][(size_t)f * lv.npix + p] = e;
+  pl.edges_orig[l][(size_t)f * lv.npix + p] = e;
+}
+
+// ---------------------------------------------------------------------------
+// a6: generateDistHistogram (imgpyramidrgbd.cpp:146-172): one block per
+// (level, tile row); u8 counters wrap like the reference's ++ on uchar.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hist(PyrGeom g, FramePlanes pl, int rows_total) {
+  __shared__ int s_cnt[128];
+  const int f = blockIdx.z;
+  // decode (level, tile row) over the levels that have a histogram
+  int l = -1, ty = blockIdx.x;
+  for (int k = 0; k < g.n_levels; ++k) {
+    if (g.lv[k].patch <= 0) continue;
+    if (ty < g.lv[k].hist_h) { l = k; break; }
+    ty -= g.lv[k].hist_h;
+  }
+  if (l < 0) return;
+  const LevelGeom lv = g.lv[l];
+  const int tid = threadIdx.x;
+  if (tid < 128) s_cnt[tid] = 0;
+  __syncthreads();
+  const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
+  const int bw = lv.hist_w * lv.patch;
+  for (int i = tid; i < lv.patch * bw; i += 256) {
+    const int y = ty * lv.patch + i / bw, x = i % bw;
+    if (edges[(size_t)y * lv.w + x] > 0) atomicAdd(&s_cnt[x / lv.patch], 1);
+  }
+  __syncthreads();
+  int nz = 0;
+  if (tid < lv.hist_w) {
+    const uint8_t v = (uint8_t)(s_cnt[tid] & 255);
+    pl.hist[l][(size_t)f * lv.hist_w * lv.hist_h + (size_t)ty * lv.hist_w + tid] = v;
+    nz = v != 0;
+  }
+  const unsigned long long m = __ballot(nz);
+  if ((tid & 63) == 0 && m) atomicAdd(&pl.hist_nz[f * REVO_L + l], __popcll(m));
+}
+
+// a7: fillInEdges (imgpyramidrgbd.cpp:111-145, gate 188-195).  Level l reads
+// the already-filled level l-1, so one 1024-thread block per frame walks the
+// levels in order.
+__global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
+  const int f = blockIdx.z;
+  for (int l = 1; l < g.n_levels; ++l) {
+    const LevelGeom lv = g.lv[l], lf = g.lv[l - 1];
+    if (!(g.use_edge_hist && lv.patch > 0 && lf.patch > 0)) continue;
+    const float frac = (float)pl.hist_nz[f * REVO_L + l] / (float)(lv.hist_w * lv.hist_h);
+    if (frac < g.n_percentage) {
+      const uint8_t* top = pl.edges[l - 1] + (size_t)f * lf.npix;
+      uint8_t* mod = pl.edges[l] + (size_t)f * lv.npix;
+      const uint8_t* hist = pl.hist[l] + (size_t)f * lv.hist_w * lv.hist_h;
+      const double thr = g.fill_thr[l];
+      // finer pixel (yy,xx) odd,odd <-> coarse pixel (yy/2, xx/2)
+      const int cw = lf.w / 2, ch = lf.h / 2;
+      for (int i = threadIdx.x; i < cw * ch; i += 1024) {
+        const int y = i / cw, x = i % cw;
+        const int yy = 2 * y + 1, xx = 2 * x + 1;
+        const int ty = yy / lf.patch, tx = xx / lf.patch;
+        if (ty >= lv.hist_h || tx >= lv.hist_w) continue;
+        if ((double)hist[(size_t)ty * lv.hist_w + tx] < thr && top[(size_t)yy * lf.w + xx] > 0)
+          mod[(size_t)y * lv.w + x] = 255;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a8: the 3-D edge list (imgpyramidrgbd.cpp:199-226) as an ORDERED stream
+// compaction: x outer / y inner (the reference's visiting order), so the list
+// is identical to the reference's, element for element.
+//   count : one thread per (column, 32-row chunk), adjacent threads = adjacent
+//           columns -> coalesced row reads
+//   scan  : one block per (frame, level), exclusive scan in column-major chunk order
+//   write : same walk, emits float4 (X,Y,Z,1) at the scanned offset
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
+  return isfinite(Z) && Z > dmin && Z < dmax;  // imgpyramidrgbd.cpp:208
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl) {
+  const int f = blockIdx.z;
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  if (gi >= g.total_cc) return;
+  const int l = level_of(g, gi, &LevelGeom::cc_base);
+  const LevelGeom lv = g.lv[l];
+  const int i = gi - lv.cc_base;
+  const int x = i % lv.w, c = i / lv.w;  // adjacent threads walk adjacent columns
+  const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
+  const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
+  const float* depth = pl.depth[l] + (size_t)f * lv.npix;
+  int* slot = pl.chunk[l] + (size_t)f * lv.w * lv.nchunk + (size_t)x * lv.nchunk + c;
+  if (!WRITE) {
+    int n = 0;
+    for (int y = yb; y < ye; ++y) {
+      const float Z = depth[(size_t)y * lv.w + x];
+      n += (edges[(size_t)y * lv.w + x] > 0 && depth_ok(Z, g.depth_min, g.depth_max)) ? 1 : 0;
+    }
+    *slot = n;
+  } else {
+    int o = *slot;
+    float4* out = pl.pts[l] + (size_t)f * lv.npix;
+    for (int y = yb; y < ye; ++y) {
+      const float Z = depth[(size_t)y * lv.w + x];
+      if (edges[(size_t)y * lv.w + x] > 0 && depth_ok(Z, g.depth_min, g.depth_max)) {
+        const float X = __fdiv_rn(Z * ((float)x - lv.cx), lv.fx);
+        const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
+        out[o++] = make_float4(X, Y, Z, 1.0f);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl) {
+  __shared__ int s_part[1024];
+  const int f = blockIdx.z, l = blockIdx.x;
+  const LevelGeom lv = g.lv[l];
+  const int n = lv.w * lv.nchunk;
+  int* a = pl.chunk[l] + (size_t)f * n;
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = tid * per, e = min(n, b + per);
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += a[i];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = (tid >= off) ? s_part[tid - off] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;  // exclusive prefix of this thread's segment
+  for (int i = b; i < e; ++i) { const int c = a[i]; a[i] = run; run += c; }
+  if (tid == 1023) pl.npts[f * REVO_L + l] = s_part[1023];
+}
+
+// ---------------------------------------------------------------------------
+// a9: cv::distanceTransform(255-edges, L2, PRECISE) (imgpyramidrgbd.cpp:241) as
+// an exact two-pass EDT.  Columns: vertical distance to the nearest edge of the
+// column (int); rows: d2(x) = min_x' (x-x')^2 + g2(x') searched outwards from x
+// with early termination once (x-x')^2 >= best -- exact, and short because DT
+// values are small wherever there are edges.  Result sqrtf(d2) is bit-identical
+// to OpenCV's (all d2 < 2^24); no edge at all -> OpenCV's 1e15f sentinel.
+// ---------------------------------------------------------------------------
+#define EDT_INF (1 << 29)
+__global__ void __launch_bounds__(128) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+  const int f = f0 + blockIdx.z * fstride;
+  const int gi = blockIdx.x * 128 + threadIdx.x;
+  if (gi >= g.total_cols) return;
+  const int l = level_of(g, gi, &LevelGeom::col_base);
+  const LevelGeom lv = g.lv[l];
+  const int x = gi - lv.col_base;
+  const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
+  int* g2 = pl.scratch[l] + (size_t)f * lv.npix;
+  int d = EDT_INF;
+  for (int y = 0; y < lv.h; ++y) {
+    d = edges[(size_t)y * lv.w + x] ? 0 : (d < EDT_INF ? d + 1 : EDT_INF);
+    g2[(size_t)y * lv.w + x] = d;
+  }
+  d = EDT_INF;
+  for (int y = lv.h - 1; y >= 0; --y) {
+    d = edges[(size_t)y * lv.w + x] ? 0 : (d < EDT_INF ? d + 1 : EDT_INF);
+    const int m = min(d, g2[(size_t)y * lv.w + x]);
+    g2[(size_t)y * lv.w + x] = m >= EDT_INF ? EDT_INF : m * m;
+  }
+}
+
+#define EDT_MAXW REVO_MAX_WIDTH
+__global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+  __shared__ int s_g2[EDT_MAXW];
+  const int f = f0 + blockIdx.z * fstride;
+  const int l = level_of(g, blockIdx.x, &LevelGeom::row_base);
+  const LevelGeom lv = g.lv[l];
+  const int y = blockIdx.x - lv.row_base;
+  const int w = lv.w;
+  const int* g2 = pl.scratch[l] + (size_t)f * lv.npix + (size_t)y * w;
+  for (int x = threadIdx.x; x < w; x += 256) s_g2[x] = g2[x];
+  __syncthreads();
+  float* dt = pl.dt[l] + (size_t)f * lv.npix + (size_t)y * w;
+  for (int x = threadIdx.x; x < w; x += 256) {
+    int best = s_g2[x];
+    for (int d = 1; d < w; ++d) {
+      const int dd = d * d;
+      if (dd >= best) break;
+      if (x - d >= 0) best = min(best, dd + s_g2[x - d]);
+      if (x + d < w) best = min(best, dd + s_g2[x + d]);
+    }
+    dt[x] = best >= EDT_INF ? __fsqrt_rn(1e15f) : __fsqrt_rn((float)best);
+  }
+}
+
+// a10: buildOptimizationStructure (imgpyramidrgbd.cpp:255-276): linear sweep
+// over [w, w*(h-1)), (0.5(prev-next), 0.5(up-down), dt, 0); rows 0 and h-1 zero.
+__global__ void __launch_bounds__(256) k_grad_table(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+  const int f = f0 + blockIdx.z * fstride;
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  if (gi >= g.total_pix) return;
+  const int l = level_of(g, gi, &LevelGeom::pix_base);
+  const LevelGeom lv = g.lv[l];
+  const int i = gi - lv.pix_base;
+  const float* dt = pl.dt[l] + (size_t)f * lv.npix;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i >= lv.w && i < lv.w * (lv.h - 1)) {
+    o.x = 0.5f * (dt[i - 1] - dt[i + 1]);
+    o.y = 0.5f * (dt[i - lv.w] - dt[i + lv.w]);
+    o.z = dt[i];
+  }
+  pl.table[l][(size_t)f * lv.npix + i] = o;
+}
+
+// ---------------------------------------------------------------------------
+// a17: assessTrackingQuality's counting maps (tracker.cpp:138-176).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vote_mark(const float4* const* cloud_pts, const int* const* cloud_n,
+                                                   const float* RT, float fx, float fy, float cx, float cy, int W,
+                                                   int H, int* marks) {
+  const int c = blockIdx.y;
+  const int n = *cloud_n[c];
+  const float* R = RT + 12 * c;
+  const float* T = R + 9;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = cloud_pts[c][i];
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q[r] = ((R[r] * p.x + R[3 + r] * p.y) + R[6 + r] * p.z) + T[r];
+    const float u = __fdiv_rn(fx * q[0], q[2]) + cx;  // tracker.cpp:153-154 operation order
+    const float v = __fdiv_rn(fy * q[1], q[2]) + cy;
+    if (u >= 0 && u < (float)W && v >= 0 && v < (float)H)
+      atomicOr(&marks[(int)floorf(v) * W + (int)floorf(u)], 1 << c);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_vote_hist(const int* marks, const uint8_t* edges, const float* depth, int npix,
+                                                   float dmin, float dmax, int* hist8) {
+  __shared__ int s_h[8];
+  if (threadIdx.x < 8) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const float Z = depth[i];
+    if (depth_ok(Z, dmin, dmax)) {
+      const int val = __popc(marks[i]);
+      atomicAdd(&s_h[val], 1);
+      if (edges[i] > 0) atomicAdd(&s_h[4 + val], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && s_h[threadIdx.x]) atomicAdd(&hist8[threadIdx.x], s_h[threadIdx.x]);
+}
+
+}  // namespace
+
+// ============================ launchers =====================================
+void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,
+                       const uint16_t* d_depth_u16, float u16_alpha, int B, hipStream_t s) {
+  const int npix = g.lv[0].npix;
+  dim3 grid((npix / 4 + 255) / 256, 1, B);
+  hipLaunchKernelGGL(k_gray_depth, grid, dim3(256), 0, s, d_bgr, d_depth_f32, d_depth_u16, u16_alpha, p.gray[0],
+                     p.depth[0], npix);
+}
+
+void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s) {
+  const LevelGeom& d = g.lv[lvl];
+  const LevelGeom& sl = g.lv[lvl - 1];
+  dim3 grid((d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, B);
+  hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h,
+                     p.depth[lvl - 1], p.depth[lvl]);
+}
+
+void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_canny_nms, dim3(g.total_tiles, 1, B), dim3(256), 0, s, g, p);
+}
+
+void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  dim3 grid((g.total_pix + 255) / 256, 1, B);
+  hipLaunchKernelGGL(k_ccl_border, grid, dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_ccl_out, grid, dim3(256), 0, s, g, p);
+}
+
+void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  int rows = 0;
+  for (int l = 0; l < g.n_levels; ++l)
+    if (g.lv[l].patch > 0) rows += g.lv[l].hist_h;
+  if (rows == 0) return;
+  hipMemsetAsync(p.hist_nz, 0, sizeof(int) * REVO_L * B, s);
+  hipLaunchKernelGGL(k_hist, dim3(rows, 1, B), dim3(256), 0, s, g, p, rows);
+  if (g.use_edge_hist && g.n_levels > 1) hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p);
+}
+
+void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  dim3 grid((g.total_cc + 255) / 256, 1, B);
+  hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels, 1, B), dim3(1024), 0, s, g, p);
+  hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(256), 0, s, g, p);
+}
+
+void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {
+  hipLaunchKernelGGL(k_edt_cols, dim3((g.total_cols + 127) / 128, 1, count), dim3(128), 0, s, g, p, f0, fstride);
+  hipLaunchKernelGGL(k_edt_rows, dim3(g.total_rows, 1, count), dim3(256), 0, s, g, p, f0, fstride);
+  hipLaunchKernelGGL(k_grad_table, dim3((g.total_pix + 255) / 256, 1, count), dim3(256), 0, s, g, p, f0, fstride);
+}
+
+void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds,
+                 const float4* const* d_cloud_pts, const int* const* d_cloud_n, const float* d_RT, int* d_marks,
+                 int* d_hist8, int use_orig_edges, hipStream_t s) {
+  const LevelGeom& lv = g.lv[lvl];
+  hipMemsetAsync(d_marks, 0, sizeof(int) * lv.npix, s);
+  hipMemsetAsync(d_hist8, 0, sizeof(int) * 8, s);
+  if (n_clouds > 0)
+    hipLaunchKernelGGL(k_vote_mark, dim3(32, n_clouds), dim3(256), 0, s, d_cloud_pts, d_cloud_n, d_RT, lv.fx, lv.fy,
+                       lv.cx, lv.cy, lv.w, lv.h, d_marks);
+  const uint8_t* edges = (use_orig_edges ? curr.edges_orig[lvl] : curr.edges[lvl]) + (size_t)curr_frame * lv.npix;
+  hipLaunchKernelGGL(k_vote_hist, dim3(16), dim3(256), 0, s, d_marks, edges,
+                     curr.depth[lvl] + (size_t)curr_frame * lv.npix, lv.npix, g.depth_min, g.depth_max, d_hist8);
+}

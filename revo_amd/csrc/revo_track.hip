@@ -1,0 +1,569 @@
+// revo_track.hip -- the edge-alignment tracker as ONE persistent kernel (gfx950).
+//
+// Replaces TrackerNew::trackFrames (tracker.cpp:294-353), checkInitializationValues
+// / evalCostFunction (tracker.cpp:265-283,357-393), Optimizer::trackFrames
+// (optimizer.cpp:235-311), calcErrorAndBuffers + calculateWarpUpdate
+// (optimizer.cpp:74-234) and LGS6 (LGSX.h:185-404).
+//
+// One 1024-thread workgroup per frame-pair runs every pyramid level and every
+// Levenberg-Marquardt iteration on the device: no host round trip between
+// residual evaluations.  The reference's two hot loops (A: warp/project/bilinear
+// gather/Huber, B: 6-vector Jacobian into the 6x6 system) are fused, so the 7
+// scratch buffers of optimizer.h:146-152 never exist: each thread keeps the 21
+// upper-triangle entries of J^T W J, the 6 of J^T W r, sum(w r^2), sum(r^2) and
+// the good count in registers, a 64-lane "reduce-scatter" butterfly folds the
+// 32 values of a wavefront with 32 shuffles (instead of 32 x 6), the 16
+// per-wave partials meet in LDS and are summed in double in a fixed order
+// (deterministic run to run), and wave 0 runs the damped 6x6 solve, SE3 exp,
+// and the accept/reject logic, publishing the next pose through LDS.
+//
+// There is no dense contraction here (a 6-vector outer product per point), so
+// no MFMA; the kernel is bound by gather latency / L2 bandwidth and by the
+// serial solve between evaluations.
+#include "revo_dev.h"
+
+namespace {
+
+enum { MODE_EVAL = 0, MODE_COST = 1, MODE_DONE = 2 };
+enum { PH_COST_EYE = 0, PH_COST_INIT = 1, PH_LEVEL_FIRST = 2, PH_LM = 3, PH_EVAL_ONLY = 4 };
+#define NWAVES (TRACK_THREADS / 64)
+#define MAX_TOTAL_EVALS 6000  // hang guard; the reference bound is 100 outer iterations x retries
+
+struct Ctrl {  // published by wave 0, read by everyone after the barrier
+  float R[9];
+  float T[3];
+  int level;
+  int mode;
+};
+
+struct W0State {  // wave-0 private LM state, kept in LDS to keep VGPRs for the hot loop
+  double Aacc[27];  // accepted normal equations: 21 upper-tri of A/n, then 6 of (sum w r v)/n
+  float q[4], t[3];    // accepted pose (Sophus::SE3f referenceToFrame)
+  float qn[4], tn[3];  // candidate pose
+  float lastErr, last_residual, lambda, incsq, costEye;
+  int iteration, incTry, phase, flags, total_evals;
+  int good, bad;
+  float sumw, sumu;
+  int evals[REVO_L];
+};
+
+// ---- small algebra (Eigen/Sophus semantics, float like the reference) -------
+__device__ __forceinline__ void quat_from_R(const float* R, float* q) {  // R column-major; q = (w,x,y,z)
+#define RM(r, c) R[(c)*3 + (r)]
+  float t = RM(0, 0) + RM(1, 1) + RM(2, 2);
+  if (t > 0.0f) {
+    t = __fsqrt_rn(t + 1.0f);
+    q[0] = 0.5f * t;
+    t = __fdiv_rn(0.5f, t);
+    q[1] = (RM(2, 1) - RM(1, 2)) * t;
+    q[2] = (RM(0, 2) - RM(2, 0)) * t;
+    q[3] = (RM(1, 0) - RM(0, 1)) * t;
+  } else if (RM(0, 0) >= RM(1, 1) && RM(0, 0) >= RM(2, 2)) {  // i = 0
+    t = __fsqrt_rn(RM(0, 0) - RM(1, 1) - RM(2, 2) + 1.0f);
+    q[1] = 0.5f * t; t = __fdiv_rn(0.5f, t);
+    q[0] = (RM(2, 1) - RM(1, 2)) * t; q[2] = (RM(1, 0) + RM(0, 1)) * t; q[3] = (RM(2, 0) + RM(0, 2)) * t;
+  } else if (RM(1, 1) > RM(0, 0) && RM(1, 1) >= RM(2, 2)) {  // i = 1
+    t = __fsqrt_rn(RM(1, 1) - RM(2, 2) - RM(0, 0) + 1.0f);
+    q[2] = 0.5f * t; t = __fdiv_rn(0.5f, t);
+    q[0] = (RM(0, 2) - RM(2, 0)) * t; q[3] = (RM(2, 1) + RM(1, 2)) * t; q[1] = (RM(0, 1) + RM(1, 0)) * t;
+  } else {  // i = 2
+    t = __fsqrt_rn(RM(2, 2) - RM(0, 0) - RM(1, 1) + 1.0f);
+    q[3] = 0.5f * t; t = __fdiv_rn(0.5f, t);
+    q[0] = (RM(1, 0) - RM(0, 1)) * t; q[1] = (RM(0, 2) + RM(2, 0)) * t; q[2] = (RM(1, 2) + RM(2, 1)) * t;
+  }
+#undef RM
+}
+
+__device__ __forceinline__ void quat_to_R(const float* q, float* R) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0f - (tyy + tzz); R[3] = txy - twz; R[6] = txz + twy;
+  R[1] = txy + twz; R[4] = 1.0f - (txx + tzz); R[7] = tyz - twx;
+  R[2] = txz - twy; R[5] = tyz + twx; R[8] = 1.0f - (txx + tyy);
+}
+
+__device__ __forceinline__ bool is_orthogonal(const float* R) {  // rotation_matrix.hpp:14-24, so3.hpp:419-424
+  float n2 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = R[r] * R[c] + R[3 + r] * R[3 + c] + R[6 + r] * R[6 + c];
+      v -= (r == c) ? 1.0f : 0.0f;
+      n2 += v * v;
+    }
+  const float det = R[0] * (R[4] * R[8] - R[7] * R[5]) - R[3] * (R[1] * R[8] - R[7] * R[2]) + R[6] * (R[1] * R[5] - R[4] * R[2]);
+  return __fsqrt_rn(n2) < 1e-5f && det > 0.0f;
+}
+
+// Sophus::SE3f::exp(inc) * (q,t)  (se3.hpp:723-745, so3.hpp:531-565, se3.hpp:317-321, so3.hpp:335-352)
+__device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, const float* t, float* qo, float* to) {
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = ox * ox + oy * oy + oz * oz;
+  const float theta = __fsqrt_rn(theta_sq);
+  float imag, real;
+  float V[9];  // row-major 3x3
+  const float O[9] = {0.f, -oz, oy, oz, 0.f, -ox, -oy, ox, 0.f};
+  float O2[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+  if (theta < 1e-5f) {
+    const float p4 = theta_sq * theta_sq;
+    imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * p4;
+    real = 1.0f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * p4;
+  } else {
+    const float h = 0.5f * theta;
+    imag = __fdiv_rn(sinf(h), theta);
+    real = cosf(h);
+  }
+  const float qe[4] = {real, imag * ox, imag * oy, imag * oz};
+  if (theta < 1e-5f) {
+    float Rm[9];
+    quat_to_R(qe, Rm);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V[r * 3 + c] = Rm[c * 3 + r];
+  } else {
+    const float ca = __fdiv_rn(1.0f - cosf(theta), theta_sq);
+    const float cb = __fdiv_rn(theta - sinf(theta), theta_sq * theta);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * O[i]) + cb * O2[i];
+  }
+  float te[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) te[r] = V[r * 3] * a[0] + V[r * 3 + 1] * a[1] + V[r * 3 + 2] * a[2];
+  // translation: te + qe (x) t   (Eigen _transformVector)
+  float uv[3] = {qe[2] * t[2] - qe[3] * t[1], qe[3] * t[0] - qe[1] * t[2], qe[1] * t[1] - qe[2] * t[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  const float c3[3] = {qe[2] * uv[2] - qe[3] * uv[1], qe[3] * uv[0] - qe[1] * uv[2], qe[1] * uv[1] - qe[2] * uv[0]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) to[r] = te[r] + (t[r] + qe[0] * uv[r] + c3[r]);
+  // rotation: qe * q, renormalised by 2/(1+|q|^2)
+  float w = qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2] - qe[3] * q[3];
+  float x = qe[0] * q[1] + qe[1] * q[0] + qe[2] * q[3] - qe[3] * q[2];
+  float y = qe[0] * q[2] + qe[2] * q[0] + qe[3] * q[1] - qe[1] * q[3];
+  float z = qe[0] * q[3] + qe[3] * q[0] + qe[1] * q[2] - qe[2] * q[1];
+  const float sn = w * w + x * x + y * y + z * z;
+  if (sn != 1.0f) {
+    const float s = __fdiv_rn(2.0f, 1.0f + sn);
+    w *= s; x *= s; y *= s; z *= s;
+  }
+  qo[0] = w; qo[1] = x; qo[2] = y; qo[3] = z;
+}
+
+// Damped 6x6 solve A(1+lambda on the diagonal) x = b in double (LDL^T, no
+// pivoting: A = J^T W J / n is positive semi-definite).  The reference solves
+// the same system with Eigen's float LDLT (optimizer.cpp:258-262); a zero /
+// invalid pivot contributes 0 like Eigen's pseudo-inverse of D.
+// Aacc: 21 upper-triangle entries (row-major) then 6 rhs.
+#define AIDX(i, j) ((i) * 6 - ((i) * ((i)-1)) / 2 + ((j) - (i)))  // upper triangle, i <= j
+__device__ __forceinline__ void solve6(const double* Aacc, float lambda, float* x) {
+  const double damp = (double)(1.0f + lambda);
+  double L[6][6], D[6], Dinv[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double dj = Aacc[AIDX(j, j)] * damp;
+#pragma unroll
+    for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * D[k];
+    D[j] = dj;
+    Dinv[j] = (dj > 1e-300) ? 1.0 / dj : 0.0;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = Aacc[AIDX(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v * Dinv[j];
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = Aacc[21 + i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] *= Dinv[i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = (float)y[i];
+}
+
+// 64-lane reduce-scatter butterfly: 32 per-lane values -> lane L ends with the
+// wave total of value (L >> 1).  32 shuffles instead of 32 x 6.
+template <int HALF, int MASK>
+__device__ __forceinline__ void butterfly_step(float* v, int lane) {
+  const bool up = (lane & MASK) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float send = up ? v[i] : v[HALF + i];
+    const float keep = up ? v[HALF + i] : v[i];
+    v[i] = keep + __shfl_xor(send, MASK);
+  }
+}
+
+// ---- the kernel ---------------------------------------------------------------
+__global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restrict__ descs, TrackParams prm,
+                                                         revo_pair_result* __restrict__ out, EvalOut* __restrict__ eval_out) {
+  __shared__ Ctrl s_ctrl;
+  __shared__ W0State s;
+  __shared__ float s_part[NWAVES][32];
+  const PairDesc& d = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  if (wave == 0) {  // ---- initial control word
+    float R0[9], T0[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[i] = d.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T0[i] = d.T[i];
+    int mode = MODE_EVAL, phase = PH_LEVEL_FIRST, level = prm.lvl_begin, flags = 0;
+    float Rp[9], Tp[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rp[i] = R0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Tp[i] = T0[i];
+    if (prm.eval_only) {
+      phase = PH_EVAL_ONLY;
+    } else if (!is_orthogonal(R0)) {  // Sophus::SE3f(R,T) would abort, optimizer.cpp:241
+      flags = 2;
+      mode = MODE_DONE;
+    } else if (prm.check_init) {
+      mode = MODE_COST; phase = PH_COST_EYE; level = prm.pyr_min_lvl;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rp[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+      Tp[0] = Tp[1] = Tp[2] = 0.0f;
+    }
+    if (lane == 0) {
+      float q0[4];
+      quat_from_R(R0, q0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.q[i] = q0[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) s.t[i] = T0[i];
+      s.lastErr = s.last_residual = __builtin_nanf("");
+      s.lambda = 0.f; s.incsq = 0.f; s.costEye = 0.f;
+      s.iteration = 0; s.incTry = 0; s.phase = phase; s.flags = flags; s.total_evals = 0;
+      s.good = 0; s.bad = 0; s.sumw = 0.f; s.sumu = 0.f;
+#pragma unroll
+      for (int i = 0; i < REVO_L; ++i) s.evals[i] = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rp[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) s_ctrl.T[i] = Tp[i];
+      s_ctrl.level = level;
+      s_ctrl.mode = mode;
+    }
+  }
+  __syncthreads();
+
+  for (;;) {
+    const int mode = s_ctrl.mode;
+    if (mode == MODE_DONE) break;
+    const int l = s_ctrl.level;
+    float R[9], T[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = s_ctrl.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = s_ctrl.T[i];
+    const float fx = prm.cam[l].fx, fy = prm.cam[l].fy, cx = prm.cam[l].cx, cy = prm.cam[l].cy;
+    const int w = prm.cam[l].w, h = prm.cam[l].h;
+    const float4* __restrict__ pts = d.pts[l];
+    const int N = d.npts[l];
+
+    if (mode == MODE_COST) {
+      // TrackerNew::evalCostFunction, tracker.cpp:357-393: nearest-pixel DT lookup
+      const float* __restrict__ dtm = d.dt_coarse;
+      const float ed = prm.edge_distance[l];
+      float cost = 0.0f;
+      for (int i = tid; i < N; i += TRACK_THREADS) {
+        const float4 p = pts[i];
+        const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
+        const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
+        const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
+        const float u = __fdiv_rn(fx * X, Z) + cx;
+        const float v = __fdiv_rn(fy * Y, Z) + cy;
+        if (u >= 0 && u < (float)w && v >= 0 && v < (float)h) {
+          const float r = dtm[(int)floorf(v) * w + (int)floorf(u)];
+          if (!(r > ed && prm.use_edge_filter)) cost += r;
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) cost += __shfl_xor(cost, m);
+      if (lane == 0) s_part[wave][0] = cost;
+    } else {
+      // calcErrorAndBuffers (optimizer.cpp:74-134) fused with calculateWarpUpdate
+      // (optimizer.cpp:197-231) and LGS6::update (LGSX.h:392-398)
+      const float4* __restrict__ tab = d.table[l];
+      const float ed = prm.edge_distance[l];
+      const float huber = prm.huber_edge;
+      const bool filt = prm.use_edge_filter != 0;
+      const float wlim = (float)(w - 2), hlim = (float)(h - 2);
+      float acc[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
+      for (int i = tid; i < N; i += TRACK_THREADS) {
+        const float4 p = pts[i];
+        const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
+        const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
+        const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
+        const float u = __fdiv_rn(X, Z) * fx + cx;
+        const float v = __fdiv_rn(Y, Z) * fy + cy;
+        if (!(u > 1.0f && v > 1.0f && u < wlim && v < hlim)) continue;  // optimizer.cpp:100
+        const int ix = (int)u, iy = (int)v;
+        const float dx = u - (float)ix, dy = v - (float)iy;
+        const float dxdy = dx * dy;
+        const float4* bp = tab + ix + iy * w;
+        const float4 t00 = bp[0], t10 = bp[1], t01 = bp[w], t11 = bp[w + 1];
+        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = ((1.0f - dx) - dy) + dxdy;
+        const float r0 = ((w11 * t11.x + w01 * t01.x) + w10 * t10.x) + w00 * t00.x;
+        const float r1 = ((w11 * t11.y + w01 * t01.y) + w10 * t10.y) + w00 * t00.y;
+        const float res = ((w11 * t11.z + w01 * t01.z) + w10 * t10.z) + w00 * t00.z;
+        if (res > ed && filt) continue;  // optimizer.cpp:108
+        const float wr = (res <= huber) ? 1.0f : __fdiv_rn(huber, res);  // optimizer.h:156-160
+        const float gx = fx * r0, gy = fy * r1;
+        const float z = __fdiv_rn(1.0f, Z), zs = __fdiv_rn(1.0f, Z * Z);
+        float jv[6];  // optimizer.cpp:218-228
+        jv[0] = z * gx;
+        jv[1] = z * gy;
+        jv[2] = (-X * zs) * gx + (-Y * zs) * gy;
+        jv[3] = (-X * Y * zs) * gx + (-(1.0f + Y * Y * zs)) * gy;
+        jv[4] = (1.0f + X * X * zs) * gx + (X * Y * zs) * gy;
+        jv[5] = (-Y * z) * gx + (X * z) * gy;
+        float wv[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) wv[a] = wr * jv[a];
+        {
+          int k = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) { acc[k] = fmaf(wv[a], jv[c], acc[k]); ++k; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] = fmaf(wv[a], res, acc[21 + a]);
+        const float r2 = res * res;
+        acc[27] = fmaf(wr, r2, acc[27]);
+        acc[28] += r2;
+        acc[29] += 1.0f;
+      }
+      butterfly_step<16, 32>(acc, lane);
+      butterfly_step<8, 16>(acc, lane);
+      butterfly_step<4, 8>(acc, lane);
+      butterfly_step<2, 4>(acc, lane);
+      butterfly_step<1, 2>(acc, lane);
+      acc[0] += __shfl_xor(acc[0], 1);
+      if ((lane & 1) == 0) s_part[wave][lane >> 1] = acc[0];
+    }
+    __syncthreads();
+
+    if (wave == 0) {  // ---- wave 0: totals, LM decision, next pose (all lanes uniform)
+      double tot = 0.0;
+      if (lane < 32) {
+#pragma unroll
+        for (int wv = 0; wv < NWAVES; ++wv) tot += (double)s_part[wv][lane];
+      }
+      int phase = s.phase;
+      int next_mode = MODE_EVAL, next_level = l;
+      bool new_candidate = false;  // solve + exp on the accepted state
+      bool level_done = false;
+      float q[4], t[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = s.q[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[i] = s.t[i];
+      float lambda = s.lambda;
+      int iteration = s.iteration, incTry = s.incTry;
+      int total_evals = s.total_evals + 1;
+      int flags = s.flags;
+
+      if (mode == MODE_COST) {
+        const float cost = (float)__shfl(tot, 0);
+        if (phase == PH_COST_EYE) {
+          if (lane == 0) s.costEye = cost;
+          phase = PH_COST_INIT;
+          next_mode = MODE_COST;
+          // next: cost at the given init pose (still in s.q/s.t as R0,T0 from the descriptor)
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = d.R[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = d.T[i];
+          }
+        } else {  // PH_COST_INIT: tracker.cpp:277-282
+          float Rs[9], Ts[3];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rs[i] = d.R[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Ts[i] = d.T[i];
+          if (s.costEye < cost) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rs[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+            Ts[0] = Ts[1] = Ts[2] = 0.0f;
+            flags |= 1;
+          }
+          quat_from_R(Rs, q);
+          t[0] = Ts[0]; t[1] = Ts[1]; t[2] = Ts[2];
+          phase = PH_LEVEL_FIRST;
+          next_mode = MODE_EVAL;
+          next_level = prm.lvl_begin;
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rs[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = Ts[i];
+          }
+        }
+      } else {
+        const double n_d = __shfl(tot, 29);
+        const double sumw_d = __shfl(tot, 27);
+        const double sumu_d = __shfl(tot, 28);
+        const int good = (int)n_d;
+        const float err = __fdiv_rn((float)sumw_d, (float)good);  // optimizer.cpp:190
+        if (lane == 0) {
+          s.good = good; s.bad = N - good; s.sumw = (float)sumw_d; s.sumu = (float)sumu_d;
+          s.evals[l] += 1;
+        }
+        bool acceptA = false;
+        if (phase == PH_EVAL_ONLY) {
+          // LGS6 after finish(): A/n, b = -(sum w r v)/n, error = sum w r^2 / n
+          const double an = tot / n_d;
+          if (lane < 27) s.Aacc[lane] = an;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          if (lane == 0) {
+            EvalOut& eo = eval_out[blockIdx.x];
+            int k = 0;
+            for (int r = 0; r < 6; ++r)
+              for (int c = r; c < 6; ++c) { const float v = (float)s.Aacc[k++]; eo.A[r * 6 + c] = v; eo.A[c * 6 + r] = v; }
+            for (int a = 0; a < 6; ++a) eo.b[a] = -(float)s.Aacc[21 + a];
+            eo.error = (float)(sumw_d / n_d);
+            eo.mean_err = err; eo.sum_w = (float)sumw_d; eo.sum_u = (float)sumu_d;
+            eo.good = good; eo.bad = N - good;
+          }
+          next_mode = MODE_DONE;
+        } else if (phase == PH_LEVEL_FIRST) {  // optimizer.cpp:243-250
+          acceptA = true;
+          if (lane == 0) { s.lastErr = err; s.last_residual = err; }
+          lambda = prm.lambda_initial[l];
+          iteration = 0;
+          if (iteration < prm.max_its[l]) { new_candidate = true; incTry = 0; } else level_done = true;
+          phase = PH_LM;
+        } else {  // PH_LM: accept / reject, optimizer.cpp:273-304
+          const float lastErr = s.lastErr;
+          if (err < lastErr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = s.qn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t[i] = s.tn[i];
+            acceptA = true;
+            if (__fdiv_rn(err, lastErr) > prm.convergence_eps[l]) iteration = prm.max_its[l];
+            if (lane == 0) { s.lastErr = err; s.last_residual = err; }
+            lambda = (lambda <= 0.2f) ? 0.0f : lambda * prm.lambda_success_fac;
+            iteration += 1;
+            if (iteration < prm.max_its[l]) { new_candidate = true; incTry = 0; } else level_done = true;
+          } else {
+            if (!(s.incsq > prm.step_size_min[l])) {
+              level_done = true;
+            } else {
+              lambda = (lambda == 0.0f) ? 0.2f : (float)((double)lambda * pow((double)prm.lambda_fail_fac, (double)incTry));
+              new_candidate = true;  // same outer iteration, incTry keeps counting
+            }
+          }
+        }
+        if (total_evals > MAX_TOTAL_EVALS && !level_done && next_mode != MODE_DONE) { level_done = true; flags |= 4; }
+        if (acceptA) {
+          const double an = tot / n_d;  // LGS6::finish, LGSX.h:320-326
+          if (lane < 27) s.Aacc[lane] = an;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (level_done) {  // optimizer.cpp:308-309 -> next level or done (tracker.cpp:324-340)
+          float Rn[9];
+          quat_to_R(q, Rn);
+          if (l > prm.lvl_end && !(flags & 4)) {
+            next_level = l - 1;
+            phase = PH_LEVEL_FIRST;
+            float q2[4];
+            quat_from_R(Rn, q2);  // Sophus::SE3f(R,T) of the next level
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = q2[i];
+          } else {
+            next_mode = MODE_DONE;
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = t[i];
+          }
+        } else if (new_candidate) {  // optimizer.cpp:258-269
+          float inc[6], qn[4], tn[3], Rn[9];
+          solve6(s.Aacc, lambda, inc);
+          incTry += 1;
+          const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
+          se3_exp_mul(inc, q, t, qn, tn);
+          quat_to_R(qn, Rn);
+          if (lane == 0) {
+            s.incsq = incsq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.qn[i] = qn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s.tn[i] = tn[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = tn[i];
+          }
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.q[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.t[i] = t[i];
+        s.lambda = lambda; s.iteration = iteration; s.incTry = incTry; s.phase = phase;
+        s.flags = flags; s.total_evals = total_evals;
+        s_ctrl.level = next_level;
+        s_ctrl.mode = next_mode;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (tid == 0 && !prm.eval_only) {
+    revo_pair_result r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.R[i] = s_ctrl.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.T[i] = s_ctrl.T[i];
+    r.err = s.last_residual;
+    r.good = s.good;
+    r.bad = s.bad;
+    // tracker.cpp:351-352
+    r.status = ((double)s.good / (double)s.bad < 4.0) ? REVO_TRACKER_STATE_NEW_KF : REVO_TRACKER_STATE_OK;
+#pragma unroll
+    for (int i = 0; i < REVO_L; ++i) r.evals[i] = s.evals[i];
+    r.flags = s.flags;
+    r.n_pts0 = d.npts[0];
+    out[blockIdx.x] = r;
+  }
+}
+
+}  // namespace
+
+void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval, int n_pairs,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(k_track, dim3(n_pairs), dim3(TRACK_THREADS), 0, s, d_descs, prm, d_out, d_eval);
+}

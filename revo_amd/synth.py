@@ -77,20 +77,37 @@ class Scene:
         side = (d_w[np.arange(n), ax] > 0).astype(np.int64)
         best_t = texit
         best_face = ax * 2 + side
-        # boxes: slab entry distance
+        # boxes: slab entry distance, evaluated only inside each box's screen-space bounding
+        # rectangle (identical result: rays outside it cannot hit the box)
+        Rt = R.T
         for b in range(self.box_lo.shape[0]):
-            t1 = (self.box_lo[b] - o) * inv
-            t2 = (self.box_hi[b] - o) * inv
+            lo, hi = self.box_lo[b], self.box_hi[b]
+            corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+            cc = (corners - t) @ Rt.T  # world -> camera
+            if np.any(cc[:, 2] < 0.05):
+                x0, x1, y0, y1 = 0, width, 0, height
+            else:
+                uu = cc[:, 0] / cc[:, 2] * fx + cx
+                vv = cc[:, 1] / cc[:, 2] * fy + cy
+                x0, x1 = int(max(0, np.floor(uu.min()) - 1)), int(min(width, np.ceil(uu.max()) + 2))
+                y0, y1 = int(max(0, np.floor(vv.min()) - 1)), int(min(height, np.ceil(vv.max()) + 2))
+                if x0 >= x1 or y0 >= y1:
+                    continue
+            idx = (np.arange(y0, y1)[:, None] * width + np.arange(x0, x1)[None, :]).reshape(-1)
+            dsub, isub = d_w[idx], inv[idx]
+            m = idx.shape[0]
+            t1 = (lo - o) * isub
+            t2 = (hi - o) * isub
             tn = np.minimum(t1, t2)
             tf = np.maximum(t1, t2)
             ax = np.argmax(tn, 1)
-            tenter = tn[np.arange(n), ax]
+            tenter = tn[np.arange(m), ax]
             texit = tf.min(1)
-            hit = (tenter < texit) & (tenter > 0.05) & (tenter < best_t)
-            side = (d_w[np.arange(n), ax] < 0).astype(np.int64)
+            hit = (tenter < texit) & (tenter > 0.05) & (tenter < best_t[idx])
+            side = (dsub[np.arange(m), ax] < 0).astype(np.int64)
             face = 6 * (1 + b) + ax * 2 + side
-            best_t = np.where(hit, tenter, best_t)
-            best_face = np.where(hit, face, best_face)
+            best_t[idx] = np.where(hit, tenter, best_t[idx])
+            best_face[idx] = np.where(hit, face, best_face[idx])
         P = o + d_w * best_t[:, None]
         ax = (best_face % 6) // 2
         # in-plane coordinates = the two axes other than the face normal

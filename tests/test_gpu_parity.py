@@ -1,0 +1,347 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Bar: bit-exact for every integer / byte / index stage and for the per-element
+float stages that keep the reference's operation order (gray, pyrDown, depth
+subsample, Canny, histogram, fill-in, ordered 3-D edge list, exact EDT, gradient
+table); stated SE(3) tolerance for the LM tracker, whose long float sums cannot
+be ordered like the reference's sequential loop:
+  per evaluation  |err - err_ref| <= 1e-4 * err_ref, A/b relative 1e-4
+  per pair        rotation within 1e-4 rad, translation within 1e-4 m of the oracle
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from revo_amd import synth  # noqa: E402
+from revo_amd.settings import (ImgPyramidSettings, OptimizerSettings, TrackerSettings, PLANE_GRAY,  # noqa: E402
+                               PLANE_DEPTH, PLANE_EDGES, PLANE_EDGES_ORIG, PLANE_DT, PLANE_GRADTABLE,
+                               PLANE_EDGES3D, PLANE_HIST)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+ROT_TOL = 1e-4  # rad
+TRANS_TOL = 1e-4  # m
+
+
+def dump(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "fail_%s.npz" % name), **arrays)
+
+
+def assert_same(name, a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or not np.array_equal(a, b, equal_nan=True):
+        dump(name, gpu=a, oracle=b)
+        n = (a != b).sum() if a.shape == b.shape else -1
+        raise AssertionError("%s differs: shapes %s %s, %d mismatching elements" % (name, a.shape, b.shape, n))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from revo_amd import api as A
+    return A
+
+
+@pytest.fixture(scope="module")
+def ro():
+    from oracle import ro as R
+    return R
+
+
+def tum_settings(levels=3):
+    return ImgPyramidSettings(pyr_min_lvl=levels - 1)
+
+
+@pytest.fixture(scope="module")
+def pair640():
+    s = tum_settings(3)
+    return s, synth.make_pair(3, s)
+
+
+def compare_pyramid(tag, gp, op, s, keyframe):
+    for lvl in range(s.nLevels()):
+        assert_same("%s_gray%d" % (tag, lvl), gp._read(PLANE_GRAY, lvl), op.read(PLANE_GRAY, lvl))
+        assert_same("%s_depth%d" % (tag, lvl), gp._read(PLANE_DEPTH, lvl), op.read(PLANE_DEPTH, lvl))
+        assert_same("%s_edgesorig%d" % (tag, lvl), gp._read(PLANE_EDGES_ORIG, lvl), op.read(PLANE_EDGES_ORIG, lvl))
+        assert_same("%s_edges%d" % (tag, lvl), gp._read(PLANE_EDGES, lvl), op.read(PLANE_EDGES, lvl))
+        if s.hist_patch[lvl] > 0:
+            assert_same("%s_hist%d" % (tag, lvl), gp._read(PLANE_HIST, lvl), op.read(PLANE_HIST, lvl))
+        assert_same("%s_pts%d" % (tag, lvl), gp.return3DEdges(lvl), op.read(PLANE_EDGES3D, lvl))
+        if keyframe:
+            assert_same("%s_dt%d" % (tag, lvl), gp.returnDistTransform(lvl), op.read(PLANE_DT, lvl))
+            assert_same("%s_table%d" % (tag, lvl), gp.returnOptimizationStructure(lvl), op.read(PLANE_GRADTABLE, lvl))
+
+
+def test_pyramid_and_keyframe_bit_exact_640(api, ro, pair640):
+    s, pair = pair640
+    cam = api.CameraPyr(s)
+    for tag, (bgr, depth) in (("ref", pair["ref"]), ("curr", pair["curr"])):
+        gp = api.ImgPyramidRGBD(s, cam, bgr, depth, 1.0)
+        op = ro.Pyramid(s, bgr, depth, 1.0)
+        gp.makeKeyframe()
+        op.makeKeyframe()
+        compare_pyramid("p640_" + tag, gp, op, s, True)
+        assert gp.returnTimestamp() == 1.0 and gp.isKeyframe()
+        n0 = gp.return3DEdges(0).shape[0]
+        assert 15000 < n0 < 40000  # the design's edge budget (iowrapperRGBD.cpp:121-122)
+
+
+@pytest.mark.parametrize("levels,hist", [(4, (20, 10, 5, 0, 0, 0)), (2, (20, 10, 0, 0, 0, 0))])
+def test_pyramid_other_level_counts(api, ro, levels, hist):
+    s = ImgPyramidSettings(pyr_min_lvl=levels - 1, hist_patch=hist)
+    bgr, depth = synth.make_pair(5, s)["ref"]
+    cam = api.CameraPyr(s)
+    gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+    op = ro.Pyramid(s, bgr, depth)
+    gp.makeKeyframe()
+    op.makeKeyframe()
+    compare_pyramid("lv%d" % levels, gp, op, s, True)
+
+
+def _edge_cases(s):
+    h, w = s.height, s.width
+    rng = np.random.default_rng(99)
+    flat = np.full((h, w, 3), 90, np.uint8)
+    d = np.full((h, w), 1.5, np.float32)
+    yield "flat", flat, d  # no edges anywhere -> DT sentinel, empty lists
+    noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)  # dense edges, huge components
+    dn = rng.uniform(0.0, 6.0, (h, w)).astype(np.float32)
+    dn[rng.uniform(0, 1, (h, w)) < 0.2] = 0.0
+    dn[5, 5] = np.nan
+    dn[6, 6] = np.inf
+    yield "noise", noise, dn
+    one = flat.copy()
+    one[:, w // 2:] = 200  # one vertical step crossing every tile row
+    one[h // 3, :] = 10  # and one horizontal line crossing every tile column
+    yield "cross", one, d
+    sparse = flat.copy()  # edges confined to a corner: low tile coverage -> fill-in path
+    sparse[: h // 6, : w // 6] = rng.integers(0, 2, (h // 6, w // 6, 1), dtype=np.uint8) * 160 + 40
+    yield "sparse", sparse, d
+    import scipy.ndimage as ndi
+    sm = ndi.gaussian_filter(rng.uniform(0, 255, (h, w)), 3.0)
+    sm = np.clip((sm - sm.mean()) * 14 + 128, 0, 255).astype(np.uint8)  # long curvy weak/strong chains
+    yield "smooth", np.repeat(sm[..., None], 3, 2), d
+
+
+def test_pyramid_edge_cases_320(api, ro):
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    for name, bgr, depth in _edge_cases(s):
+        gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+        op = ro.Pyramid(s, bgr, depth)
+        gp.makeKeyframe()
+        op.makeKeyframe()
+        compare_pyramid("edge_" + name, gp, op, s, True)
+    # the cross case must actually have exercised fillInEdges at level 1
+    bgr, depth = [c for c in _edge_cases(s) if c[0] == "cross"][0][1:]
+    op = ro.Pyramid(s, bgr, depth)
+    assert not np.array_equal(op.read(PLANE_EDGES, 1), op.read(PLANE_EDGES_ORIG, 1))
+
+
+def test_u16_depth_entry_point(api, ro):
+    s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
+    bgr, depth = synth.make_pair(1, s)["ref"]
+    raw = np.clip(depth * 5000.0, 0, 65535).astype(np.uint16)
+    cam = api.CameraPyr(s)
+    gp = api.ImgPyramidRGBD(s, cam, bgr, raw, depth_scale_factor=5000.0)
+    op = ro.Pyramid(s, bgr, ro.u16_to_depth(raw, 5000.0))
+    compare_pyramid("u16", gp, op, s, False)
+
+
+def _setup_pair(api, ro, s, pair, trk_settings=None):
+    cam = api.CameraPyr(s)
+    g_ref = api.ImgPyramidRGBD(s, cam, *pair["ref"])
+    g_cur = api.ImgPyramidRGBD(s, cam, *pair["curr"])
+    g_ref.makeKeyframe()
+    o_ref = ro.Pyramid(s, *pair["ref"])
+    o_cur = ro.Pyramid(s, *pair["curr"])
+    o_ref.makeKeyframe()
+    ts = trk_settings or TrackerSettings()
+    gt = api.TrackerNew(ts, s, cam)
+    ot = ro.Tracker(s, OptimizerSettings(), ts)
+    return cam, g_ref, g_cur, o_ref, o_cur, gt, ot
+
+
+def rot_angle(Ra, Rb):
+    d = np.asarray(Ra, np.float64).T @ np.asarray(Rb, np.float64)
+    return float(np.arccos(np.clip((np.trace(d) - 1) / 2, -1, 1)))
+
+
+def test_residual_and_normal_equations_parity(api, ro, pair640):
+    s, pair = pair640
+    cam, g_ref, g_cur, o_ref, o_cur, gt, ot = _setup_pair(api, ro, s, pair)
+    gt_T = pair["T_ref_curr"]
+    poses = [(np.eye(3), np.zeros(3)), (gt_T[:3, :3], gt_T[:3, 3]),
+             (synth.se3_exp([0.02, -0.01, 0.03, 0.01, -0.02, 0.015])[:3, :3], np.array([0.02, -0.01, 0.03]))]
+    ro.lib().ro_set_accum_double(1)  # compare against the well-rounded sums, then the faithful ones
+    try:
+        for lvl in range(3):
+            for k, (R, T) in enumerate(poses):
+                e_g, info_g, A_g, b_g = gt.mOptimizer.evalAt(g_ref, g_cur, R, T, lvl)
+                e_o, info_o, A_o, b_o = ot.eval(o_ref, o_cur, R, T, lvl)
+                assert info_g.good_pts_edges == info_o.good_pts_edges, (lvl, k)
+                assert info_g.bad_pts_edges == info_o.bad_pts_edges, (lvl, k)
+                assert abs(e_g - e_o) <= 1e-5 * abs(e_o), (lvl, k, e_g, e_o)
+                scale = np.sqrt(np.outer(np.diag(A_o), np.diag(A_o)))
+                assert np.all(np.abs(A_g - A_o) <= 1e-4 * scale), (lvl, k)
+                assert np.all(np.abs(b_g - b_o) <= 1e-4 * np.sqrt(np.diag(A_o)) * max(1.0, np.sqrt(e_o))), (lvl, k)
+    finally:
+        ro.lib().ro_set_accum_double(0)
+    for lvl in range(3):  # faithful float sums: the SURVEY 8a per-evaluation tolerance
+        e_g, info_g, _, _ = gt.mOptimizer.evalAt(g_ref, g_cur, *poses[0], lvl)
+        e_o, info_o, _, _ = ot.eval(o_ref, o_cur, *poses[0], lvl)
+        assert abs(e_g - e_o) <= 1e-4 * abs(e_o)
+
+
+def test_track_level_and_track_frames_parity(api, ro, pair640):
+    s, pair = pair640
+    cam, g_ref, g_cur, o_ref, o_cur, gt, ot = _setup_pair(api, ro, s, pair)
+    # one level from identity (Optimizer::trackFrames)
+    for lvl in (2, 1):
+        e_g, R_g, T_g = gt.mOptimizer.trackFrames(g_ref, g_cur, np.eye(3), np.zeros(3), lvl)
+        R_o, T_o, e_o, info_o, ev_o, ab = ot.track_level(o_ref, o_cur, np.eye(3), np.zeros(3), lvl)
+        assert rot_angle(R_g, R_o) < 5 * ROT_TOL and np.linalg.norm(T_g - T_o) < 5 * TRANS_TOL, (lvl, T_g, T_o)
+    # full coarse-to-fine (TrackerNew::trackFrames)
+    st_g, R_g, T_g, err_g = gt.trackFrames(np.eye(3), np.zeros(3), g_ref, g_cur)
+    r_o = ot.trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
+    dr, dt = rot_angle(R_g, r_o["R"]), float(np.linalg.norm(T_g - r_o["T"]))
+    gr, gtr = synth.pose_error(R_g, T_g, pair["T_ref_curr"])
+    print("GPU vs oracle: %.2e rad %.2e m; GPU vs ground truth: %.2e rad %.2e m; evals gpu %s oracle %s"
+          % (dr, dt, gr, gtr, gt.last_evals.tolist(), r_o["evals"].tolist()))
+    assert dr < ROT_TOL and dt < TRANS_TOL
+    assert st_g == r_o["status"]
+    assert abs(err_g - r_o["err"]) <= 2e-3 * r_o["err"]
+    assert gr < 2e-3 and gtr < 2e-3
+    # deterministic: same call, same bits
+    st2, R2, T2, err2 = gt.trackFrames(np.eye(3), np.zeros(3), g_ref, g_cur)
+    assert np.array_equal(R2, R_g) and np.array_equal(T2, T_g) and err2 == err_g
+
+
+def test_init_check_resets_bad_prior(api, ro, pair640):
+    s, pair = pair640
+    cam, g_ref, g_cur, o_ref, o_cur, gt, ot = _setup_pair(api, ro, s, pair)
+    bad = synth.se3_exp([0.25, 0.1, 0.0, 0.0, 0.12, 0.0])  # far-off prior: identity must win (tracker.cpp:277-282)
+    st_g, R_g, T_g, err_g = gt.trackFrames(bad[:3, :3], bad[:3, 3], g_ref, g_cur)
+    r_o = ot.trackFrames(o_ref, o_cur, bad[:3, :3], bad[:3, 3])
+    assert r_o["flags"] & 1
+    assert rot_angle(R_g, r_o["R"]) < ROT_TOL and np.linalg.norm(T_g - r_o["T"]) < TRANS_TOL
+
+
+def test_assess_tracking_quality_parity(api, ro, pair640):
+    s, pair = pair640
+    cam, g_ref, g_cur, o_ref, o_cur, gt, ot = _setup_pair(api, ro, s, pair)
+    assert gt.assessTrackingQuality(np.eye(4), g_cur) == 0  # empty past list -> OK (tracker.cpp:121)
+    poses = [np.eye(4), synth.se3_exp([0.01, 0, 0.02, 0, 0.01, 0]), pair["T_ref_curr"], synth.se3_exp([0.3, 0, 0, 0, 0.2, 0])]
+    for k, P in enumerate(poses):
+        src_g, src_o = (g_ref, o_ref) if k % 2 == 0 else (g_cur, o_cur)
+        gt.addOldPclAndPose(src_g, 2, P, float(k))
+        ot.addOldPclAndPose(src_o, 2, P, float(k))
+        st_g, h_g, o_g = gt.assessTrackingQuality(pair["T_ref_curr"], g_cur, return_hist=True)
+        st_o, h_o, o_o = ot.assessTrackingQuality(pair["T_ref_curr"], o_cur)
+        assert np.array_equal(h_g, h_o) and np.array_equal(o_g, o_o), (k, h_g, h_o, o_g, o_o)
+        assert st_g == st_o
+    assert gt.pastSize() == 4
+    gt.clearUpPastLists()
+    ot.clearUpPastLists()
+    assert gt.pastSize() == ot.past_size() == 3
+    st_g, h_g, o_g = gt.assessTrackingQuality(pair["T_ref_curr"], g_cur, return_hist=True)
+    st_o, h_o, o_o = ot.assessTrackingQuality(pair["T_ref_curr"], o_cur)
+    assert np.array_equal(h_g, h_o) and np.array_equal(o_g, o_o) and st_g == st_o
+
+
+def test_error_behaviour(api, pair640):
+    s, pair = pair640
+    cam = api.CameraPyr(s)
+    a = api.ImgPyramidRGBD(s, cam, *pair["ref"])
+    b = api.ImgPyramidRGBD(s, cam, *pair["curr"])
+    trk = api.TrackerNew(TrackerSettings(), s, cam)
+    with pytest.raises(api.RevoError) as e:  # imgpyramidrgbd.h:113-116 "optimizationStructure not built!"
+        trk.trackFrames(np.eye(3), np.zeros(3), a, b)
+    assert e.value.code == -3
+    with pytest.raises(api.RevoError):
+        a.returnDistTransform(0)
+    a.makeKeyframe()
+    Rbad = np.eye(3)
+    Rbad[0, 1] = 0.01
+    with pytest.raises(api.RevoError) as e:  # Sophus SO3(R) ENSURE -> abort() in the reference
+        trk.trackFrames(Rbad, np.zeros(3), a, b)
+    assert e.value.code == -4
+    with pytest.raises(api.RevoError):
+        a.returnGray(7)
+    with pytest.raises(ValueError):
+        api.ImgPyramidRGBD(s, cam, np.zeros((10, 10, 3), np.uint8), np.zeros((10, 10), np.float32))
+    with pytest.raises(api.RevoError):
+        api.CameraPyr(ImgPyramidSettings(width=641))
+
+
+def test_empty_edge_list_is_safe(api, ro):
+    """N = 0: the reference divides by zero (optimizer.cpp:190, LGSX.h:323-325); both sides must
+    terminate and report the same counts."""
+    s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
+    flat = np.full((120, 160, 3), 128, np.uint8)
+    d = np.full((120, 160), 2.0, np.float32)
+    pair = synth.make_pair(2, s)
+    cam = api.CameraPyr(s)
+    g_ref = api.ImgPyramidRGBD(s, cam, *pair["ref"])
+    g_ref.makeKeyframe()
+    g_cur = api.ImgPyramidRGBD(s, cam, flat, d)
+    trk = api.TrackerNew(TrackerSettings(), s, cam)
+    st, R, T, err = trk.trackFrames(np.eye(3), np.zeros(3), g_ref, g_cur)
+    assert trk.last_info.good_pts_edges == 0 and trk.last_info.bad_pts_edges == 0
+    assert np.isnan(err) and np.allclose(R, np.eye(3)) and np.all(T == 0)
+
+
+def test_batch_matches_single_and_full_size_properties(api, ro):
+    import torch
+    s = tum_settings(4)
+    s.hist_patch[3] = 0
+    n_pairs = 4
+    pairs = [synth.make_pair(100 + i, s) for i in range(n_pairs)]
+    cam = api.CameraPyr(s)
+    trk = api.TrackerNew(TrackerSettings(), s, cam)
+    bgr = np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])
+    dep = np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])
+    d_bgr = torch.from_numpy(bgr).cuda()
+    d_dep = torch.from_numpy(dep).cuda()
+    d_res = torch.zeros(n_pairs * 96, dtype=torch.uint8, device="cuda")
+    bt = api.BatchTracker(cam, n_pairs)
+    bt.track(d_bgr.data_ptr(), d_dep.data_ptr(), d_res.data_ptr())
+    bt.sync()
+    res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), n_pairs)
+    for i, p in enumerate(pairs):
+        g_ref = api.ImgPyramidRGBD(s, cam, *p["ref"])
+        g_cur = api.ImgPyramidRGBD(s, cam, *p["curr"])
+        g_ref.makeKeyframe()
+        st, R, T, err = trk.trackFrames(np.eye(3), np.zeros(3), g_ref, g_cur)
+        assert np.array_equal(res[i]["R"], R) and np.array_equal(res[i]["T"], T) and res[i]["err"] == err
+        assert res[i]["status"] == st and np.array_equal(res[i]["evals"], trk.last_evals)
+        # batch planes == single-frame planes, bit for bit
+        view = bt.frame(2 * i + 1, s)
+        for lvl in range(4):
+            assert np.array_equal(view.return3DEdges(lvl), g_cur.return3DEdges(lvl))
+            assert np.array_equal(view.returnEdges(lvl), g_cur.returnEdges(lvl))
+        kf = bt.frame(2 * i, s)
+        assert np.array_equal(kf.returnOptimizationStructure(0), g_ref.returnOptimizationStructure(0))
+        # size-independent properties at the full 640x480 size
+        dt0 = kf.returnDistTransform(0)
+        e0 = kf.returnEdges(0)
+        assert np.all(dt0[e0 > 0] == 0) and np.all(dt0[e0 == 0] >= 1)
+        gy, gx = np.abs(np.diff(dt0, axis=0)), np.abs(np.diff(dt0, axis=1))
+        assert gy.max() <= 1.0 + 1e-6 and gx.max() <= 1.0 + 1e-6  # EDT is 1-Lipschitz
+        pts = view.return3DEdges(0)
+        u = pts[:, 0] / pts[:, 2] * s.fx + s.cx
+        v = pts[:, 1] / pts[:, 2] * s.fy + s.cy
+        lin = np.rint(u).astype(np.int64) * s.height + np.rint(v).astype(np.int64)
+        assert np.all(np.diff(lin) > 0)  # strictly column-major order, no duplicates
+        er, et = synth.pose_error(res[i]["R"], res[i]["T"], p["T_ref_curr"])
+        assert er < 2e-3 and et < 3e-3, (i, er, et)
+    # oracle parity for the 4-level configuration on pair 0
+    o_ref = ro.Pyramid(s, *pairs[0]["ref"])
+    o_cur = ro.Pyramid(s, *pairs[0]["curr"])
+    o_ref.makeKeyframe()
+    r_o = ro.Tracker(s).trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
+    assert rot_angle(res[0]["R"], r_o["R"]) < ROT_TOL and np.linalg.norm(res[0]["T"] - r_o["T"]) < TRANS_TOL
