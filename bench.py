@@ -89,7 +89,12 @@ def main():
     d_dep = torch.from_numpy(dep).to(dev)
     d_res = torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev)
     d_all = torch.zeros(world * a.pairs * 96, dtype=torch.uint8, device=dev) if world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # an explicit (non-null) torch stream: the HIP kernels, torch's events and the RCCL
+    # collective are all ordered on it
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def step():
         bt.track(d_bgr.data_ptr(), d_dep.data_ptr(), d_res.data_ptr(), stream=stream)

@@ -46,6 +46,13 @@ def lib():
         raise ImportError(
             "revo_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    # torch (device memory / streams / torch.distributed plumbing) bundles its own ROCm
+    # runtime; loading it FIRST makes librevo_hip.so bind to that single copy instead of
+    # mixing it with /opt/rocm's (two HIP runtimes in one process corrupt the heap).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     L.revo_last_error.restype = C.c_char_p
     L.revo_version.restype = C.c_char_p

@@ -1,0 +1,254 @@
+// revo_adapters.hpp -- header-only C++ adapters over the C ABI (include/revo_hip.h).
+//
+// Re-creates the reference's class names and method surface so a system.cpp-style
+// host links against librevo_hip.so instead of datastructures/imgpyramidrgbd.cpp,
+// system/tracker.cpp, system/optimizer.cpp and utils/LGSX.h:
+//
+//   ImgPyramidSettings / Camera / CameraPyr   datastructures/camerapyr.h:27-193
+//   ImgPyramidRGBD                            datastructures/imgpyramidrgbd.h:27-250
+//   OptimizerSettings / Optimizer             system/optimizer.h:42-186
+//   TrackerSettings / TrackerNew              system/tracker.h:31-105
+//
+// No Eigen / OpenCV dependency: matrices are passed as anything with .data()
+// (Eigen::Matrix3f / Vector3f / Matrix4f are column-major, which is what the ABI
+// wants) and images as anything with .data and .step (cv::Mat) or raw pointers.
+// Error behaviour follows the reference: a failing call logs and exit(0)s
+// (imgpyramidrgbd.h:115-116, camerapyr.h:34-38), a non-orthogonal R abort()s
+// (Sophus ENSURE, common.hpp:117-136).  Define REVO_ADAPTERS_THROW to get
+// std::runtime_error instead.
+#pragma once
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/revo_hip.h"
+
+namespace revo {
+
+inline void fatal(int rc, const char* what) {
+#ifdef REVO_ADAPTERS_THROW
+  throw std::runtime_error(std::string(what) + ": " + revo_last_error());
+#else
+  std::fprintf(stderr, "[revo] %s: %s\n", what, revo_last_error());
+  if (rc == REVO_ERR_NOT_ORTHOGONAL) std::abort();  // Sophus SOPHUS_ENSURE
+  std::exit(0);                                     // the reference's I3D_LOG(error) + exit(0)
+#endif
+}
+inline void check(int rc, const char* what) { if (rc != REVO_OK) fatal(rc, what); }
+
+// ---- settings ------------------------------------------------------------------
+struct ImgPyramidSettings : revo_pyr_settings {  // camerapyr.h:27-89
+  ImgPyramidSettings() { revo_pyr_settings_default(this); }
+  int nLevels() const { return pyr_min_lvl - pyr_max_lvl + 1; }  // camerapyr.h:68-71
+  int& PYR_MIN_LVL() { return pyr_min_lvl; }
+  int& PYR_MAX_LVL() { return pyr_max_lvl; }
+};
+struct OptimizerSettings : revo_opt_settings {  // optimizer.h:42-112
+  OptimizerSettings() { revo_opt_settings_default(this); }
+};
+struct TrackerSettings : revo_tracker_settings {  // tracker.h:31-55
+  OptimizerSettings optimizerSettings;
+  TrackerSettings() { revo_tracker_settings_default(this); }
+};
+
+struct Camera {  // camerapyr.h:90-111
+  float fx, fy, cx, cy;
+  size_t width, height, area;
+};
+
+// ---- CameraPyr: intrinsics per level + owner of the device context -------------
+class CameraPyr {  // camerapyr.h:113-193
+ public:
+  explicit CameraPyr(const ImgPyramidSettings& settingsPyr, int device = 0) {
+    check(revo_ctx_create(device, &settingsPyr, nullptr, nullptr, &ctx_), "CameraPyr");
+    for (int lvl = 0; lvl < settingsPyr.nLevels(); ++lvl) {
+      float k[6];
+      check(revo_ctx_camera(ctx_, lvl, k), "CameraPyr::at");
+      camPyr.push_back(Camera{k[0], k[1], k[2], k[3], (size_t)k[4], (size_t)k[5], (size_t)k[4] * (size_t)k[5]});
+    }
+  }
+  ~CameraPyr() { revo_ctx_destroy(ctx_); }
+  CameraPyr(const CameraPyr&) = delete;
+  CameraPyr& operator=(const CameraPyr&) = delete;
+  int size() const { return (int)camPyr.size(); }
+  const Camera& at(int lvl) const { return camPyr.at(lvl); }
+  revo_ctx* ctx() const { return ctx_; }
+  std::vector<Camera> camPyr;
+
+ private:
+  revo_ctx* ctx_ = nullptr;
+};
+
+// ---- ImgPyramidRGBD ---------------------------------------------------------------
+class ImgPyramidRGBD {  // imgpyramidrgbd.h:27-250
+ public:
+  // raw-pointer form of ImgPyramidRGBD(settings, camPyr, fullResRgb, fullResDepth, timestamp)
+  ImgPyramidRGBD(const ImgPyramidSettings& settings, const std::shared_ptr<CameraPyr>& camPyr, const uint8_t* bgr,
+                 size_t bgr_stride, const float* depth_m, size_t depth_stride, double timestamp)
+      : cameraPyr(camPyr), mSettings(settings) {
+    check(revo_pyramid_create(camPyr->ctx(), bgr, bgr_stride, depth_m, depth_stride, timestamp, &pyr_), "ImgPyramidRGBD");
+    setIdentity();
+  }
+  // cv::Mat-like form (anything with .data and .step): BGR8 + CV_32FC1 metres
+  template <class MatRGB, class MatDepth>
+  ImgPyramidRGBD(const ImgPyramidSettings& settings, const std::shared_ptr<CameraPyr>& camPyr, const MatRGB& fullResRgb,
+                 const MatDepth& fullResDepth, double timestamp)
+      : ImgPyramidRGBD(settings, camPyr, (const uint8_t*)fullResRgb.data, (size_t)fullResRgb.step,
+                       (const float*)fullResDepth.data, (size_t)fullResDepth.step, timestamp) {}
+  ~ImgPyramidRGBD() { revo_pyramid_destroy(pyr_); }
+  ImgPyramidRGBD(const ImgPyramidRGBD&) = delete;
+  ImgPyramidRGBD& operator=(const ImgPyramidRGBD&) = delete;
+
+  void makeKeyframe() { check(revo_pyramid_make_keyframe(pyr_), "makeKeyframe"); }  // imgpyramidrgbd.cpp:231-252
+  void prepareKfForStorage() {}                                                      // imgpyramidrgbd.h:156-169 (no-op)
+
+  // accessors: lazy device->host copies (imgpyramidrgbd.h:45-117)
+  std::vector<float> return3DEdges(unsigned lvl) const { return readF(REVO_PLANE_EDGES3D, lvl, 4); }  // 4 x N col-major
+  std::vector<float> returnOptimizationStructure(unsigned lvl) const { return readF(REVO_PLANE_GRADTABLE, lvl, 4); }
+  std::vector<float> returnDistTransform(unsigned lvl) const { return readF(REVO_PLANE_DT, lvl, 1); }
+  std::vector<float> returnDepth(unsigned lvl) const { return readF(REVO_PLANE_DEPTH, lvl, 1); }
+  std::vector<uint8_t> returnEdges(unsigned lvl) const { return readU8(REVO_PLANE_EDGES, lvl); }
+  std::vector<uint8_t> returnOrigEdges(unsigned lvl) const { return readU8(REVO_PLANE_EDGES_ORIG, lvl); }
+  std::vector<uint8_t> returnGray(unsigned lvl) const { return readU8(REVO_PLANE_GRAY, lvl); }
+  std::array<float, 9> returnK(unsigned lvl) const {  // column-major 3x3
+    const Camera& c = cameraPyr->at((int)lvl);
+    return {c.fx, 0, 0, 0, c.fy, 0, c.cx, c.cy, 1};
+  }
+  double returnTimestamp() const { return revo_pyramid_timestamp(pyr_); }
+  unsigned returnMaxLvl() const { return (unsigned)mSettings.pyr_max_lvl; }
+  unsigned returnMinLvl() const { return (unsigned)mSettings.pyr_min_lvl; }
+
+  // pose bookkeeping (imgpyramidrgbd.h:126-151), column-major 4x4
+  template <class M4> void setTwf(const M4& T) { std::memcpy(T_w_f, T.data(), sizeof(T_w_f)); }
+  void setTwf(const float* T16) { std::memcpy(T_w_f, T16, sizeof(T_w_f)); }
+  const float* getTransKFtoWorld() const { return T_w_f; }
+
+  int frameId = 0;
+  std::shared_ptr<CameraPyr> cameraPyr;
+  revo_pyr* handle() const { return pyr_; }
+
+ private:
+  void setIdentity() { std::memset(T_w_f, 0, sizeof(T_w_f)); T_w_f[0] = T_w_f[5] = T_w_f[10] = T_w_f[15] = 1.f; }
+  std::vector<float> readF(revo_plane what, unsigned lvl, int k) const {
+    size_t n = 0;
+    check(revo_pyramid_read(pyr_, what, (int)lvl, nullptr, 0, &n), "accessor");
+    std::vector<float> v(n * k);
+    if (n) check(revo_pyramid_read(pyr_, what, (int)lvl, v.data(), v.size() * sizeof(float), &n), "accessor");
+    return v;
+  }
+  std::vector<uint8_t> readU8(revo_plane what, unsigned lvl) const {
+    size_t n = 0;
+    check(revo_pyramid_read(pyr_, what, (int)lvl, nullptr, 0, &n), "accessor");
+    std::vector<uint8_t> v(n);
+    if (n) check(revo_pyramid_read(pyr_, what, (int)lvl, v.data(), v.size(), &n), "accessor");
+    return v;
+  }
+  ImgPyramidSettings mSettings;
+  revo_pyr* pyr_ = nullptr;
+  float T_w_f[16];
+};
+
+// ---- Optimizer -------------------------------------------------------------------
+class Optimizer {  // optimizer.h:114-186
+ public:
+  struct ResidualInfo : revo_residual_info {  // optimizer.h:118-140
+    ResidualInfo() { clearAll(); }
+    void clearAll() { good_pts_edges = bad_pts_edges = 0; sum_error_unweighted = sum_error_weighted = 0.f; }
+    int& goodPtsEdges() { return good_pts_edges; }
+    int& badPtsEdges() { return bad_pts_edges; }
+  };
+  Optimizer(const OptimizerSettings& settings, const std::shared_ptr<CameraPyr>& cam) : mSettings(settings), cam_(cam) {}
+  // float trackFrames(refFrame, currFrame, Matrix3f& R, Vector3f& T, int lvl, ResidualInfo&), optimizer.cpp:235-311
+  template <class M3, class V3>
+  float trackFrames(const std::shared_ptr<ImgPyramidRGBD>& refFrame, const std::shared_ptr<ImgPyramidRGBD>& currFrame, M3& R,
+                    V3& T, int lvl, ResidualInfo& resInfo) {
+    float err = 0.f;
+    check(revo_optimizer_track_level(cam_->ctx(), refFrame->handle(), currFrame->handle(), R.data(), T.data(), lvl, &resInfo, &err),
+          "Optimizer::trackFrames");
+    return err;
+  }
+
+ private:
+  OptimizerSettings mSettings;
+  std::shared_ptr<CameraPyr> cam_;
+};
+
+// ---- TrackerNew ------------------------------------------------------------------
+class TrackerNew {  // tracker.h:56-105
+ public:
+  enum TrackerStatus { TRACKER_STATE_OK, TRACKER_STATE_LOST, TRACKER_STATE_NEW_KF, TRACKER_STATE_UNKNOWN };
+  int histogramLevel;
+  // TrackerNew(const TrackerSettings&, const ImgPyramidSettings&) + the shared CameraPyr (device context)
+  TrackerNew(const TrackerSettings& config, const ImgPyramidSettings& pyrConfig, const std::shared_ptr<CameraPyr>& cam)
+      : histogramLevel(config.histogram_level), mSettings(config), mPyrConfig(pyrConfig), cam_(cam),
+        mOptimizer(config.optimizerSettings, cam) {
+    check(revo_ctx_set_tracker(cam->ctx(), &config.optimizerSettings, &config), "TrackerNew");
+  }
+  // tracker.cpp:294-353
+  template <class M3, class V3>
+  TrackerStatus trackFrames(M3& R, V3& T, float& error, const std::shared_ptr<ImgPyramidRGBD>& refFrame,
+                            const std::shared_ptr<ImgPyramidRGBD>& currFrame) {
+    int status = TRACKER_STATE_UNKNOWN;
+    check(revo_tracker_track_frames(cam_->ctx(), refFrame->handle(), currFrame->handle(), R.data(), T.data(), &error, &status,
+                                    nullptr, lastEvals),
+          "TrackerNew::trackFrames");
+    return (TrackerStatus)status;
+  }
+  // tracker.cpp:118-201
+  template <class M4>
+  TrackerStatus assessTrackingQuality(const M4& estimatedPose, const std::shared_ptr<ImgPyramidRGBD>& currFrame) {
+    int status = TRACKER_STATE_OK;
+    check(revo_tracker_assess_quality(cam_->ctx(), estimatedPose.data(), currFrame->handle(), &status, nullptr, nullptr),
+          "assessTrackingQuality");
+    return (TrackerStatus)status;
+  }
+  // tracker.cpp:209-223: the reference passes frame->return3DEdges(lvl); here the cloud stays in HBM,
+  // so the source pyramid and the level are passed instead
+  template <class M4>
+  void addOldPclAndPose(const std::shared_ptr<ImgPyramidRGBD>& src, int lvl, const M4& worldPose, double timeStamp) {
+    check(revo_tracker_add_old_pcl(cam_->ctx(), src->handle(), lvl, worldPose.data(), timeStamp), "addOldPclAndPose");
+  }
+  void clearUpPastLists() { check(revo_tracker_clear_past(cam_->ctx()), "clearUpPastLists"); }  // tracker.cpp:248-257
+  int32_t lastEvals[REVO_MAX_LEVELS] = {0, 0, 0, 0, 0, 0};
+
+ private:
+  TrackerSettings mSettings;
+  ImgPyramidSettings mPyrConfig;
+  std::shared_ptr<CameraPyr> cam_;
+  Optimizer mOptimizer;
+};
+
+// ---- tiny column-major helpers for hosts without Eigen ---------------------------
+struct Mat3f { float m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; float* data() { return m; } const float* data() const { return m; } };
+struct Vec3f { float v[3] = {0, 0, 0}; float* data() { return v; } const float* data() const { return v; } };
+struct Mat4f {
+  float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float* data() { return m; }
+  const float* data() const { return m; }
+  static Mat4f fromRT(const Mat3f& R, const Vec3f& T) {  // transformFromRT, system.h
+    Mat4f o;
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) o.m[c * 4 + r] = R.m[c * 3 + r];
+    o.m[12] = T.v[0]; o.m[13] = T.v[1]; o.m[14] = T.v[2];
+    return o;
+  }
+  Mat4f operator*(const Mat4f& B) const {
+    Mat4f o;
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r)
+        o.m[c * 4 + r] = m[r] * B.m[c * 4] + m[4 + r] * B.m[c * 4 + 1] + m[8 + r] * B.m[c * 4 + 2] + m[12 + r] * B.m[c * 4 + 3];
+    return o;
+  }
+  Mat4f inverseRigid() const {  // inverse of a rigid transform
+    Mat4f o;
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) o.m[c * 4 + r] = m[r * 4 + c];
+    for (int r = 0; r < 3; ++r) o.m[12 + r] = -(o.m[r] * m[12] + o.m[4 + r] * m[13] + o.m[8 + r] * m[14]);
+    return o;
+  }
+};
+
+}  // namespace revo

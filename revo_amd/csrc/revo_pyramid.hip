@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int
       if (x - d >= 0) best = min(best, dd + s_g2[x - d]);
       if (x + d < w) best = min(best, dd + s_g2[x + d]);
     }
-    dt[x] = best >= EDT_INF ? __fsqrt_rn(1e15f) : __fsqrt_rn((float)best);
+    dt[x] = best >= EDT_INF ? sqrtf(1e15f) : sqrtf((float)best);
   }
 }
 

@@ -52,22 +52,22 @@ __device__ __forceinline__ void quat_from_R(const float* R, float* q) {  // R co
 #define RM(r, c) R[(c)*3 + (r)]
   float t = RM(0, 0) + RM(1, 1) + RM(2, 2);
   if (t > 0.0f) {
-    t = __fsqrt_rn(t + 1.0f);
+    t = sqrtf(t + 1.0f);
     q[0] = 0.5f * t;
     t = __fdiv_rn(0.5f, t);
     q[1] = (RM(2, 1) - RM(1, 2)) * t;
     q[2] = (RM(0, 2) - RM(2, 0)) * t;
     q[3] = (RM(1, 0) - RM(0, 1)) * t;
   } else if (RM(0, 0) >= RM(1, 1) && RM(0, 0) >= RM(2, 2)) {  // i = 0
-    t = __fsqrt_rn(RM(0, 0) - RM(1, 1) - RM(2, 2) + 1.0f);
+    t = sqrtf(RM(0, 0) - RM(1, 1) - RM(2, 2) + 1.0f);
     q[1] = 0.5f * t; t = __fdiv_rn(0.5f, t);
     q[0] = (RM(2, 1) - RM(1, 2)) * t; q[2] = (RM(1, 0) + RM(0, 1)) * t; q[3] = (RM(2, 0) + RM(0, 2)) * t;
   } else if (RM(1, 1) > RM(0, 0) && RM(1, 1) >= RM(2, 2)) {  // i = 1
-    t = __fsqrt_rn(RM(1, 1) - RM(2, 2) - RM(0, 0) + 1.0f);
+    t = sqrtf(RM(1, 1) - RM(2, 2) - RM(0, 0) + 1.0f);
     q[2] = 0.5f * t; t = __fdiv_rn(0.5f, t);
     q[0] = (RM(0, 2) - RM(2, 0)) * t; q[3] = (RM(2, 1) + RM(1, 2)) * t; q[1] = (RM(0, 1) + RM(1, 0)) * t;
   } else {  // i = 2
-    t = __fsqrt_rn(RM(2, 2) - RM(0, 0) - RM(1, 1) + 1.0f);
+    t = sqrtf(RM(2, 2) - RM(0, 0) - RM(1, 1) + 1.0f);
     q[3] = 0.5f * t; t = __fdiv_rn(0.5f, t);
     q[0] = (RM(1, 0) - RM(0, 1)) * t; q[1] = (RM(0, 2) + RM(2, 0)) * t; q[2] = (RM(1, 2) + RM(2, 1)) * t;
   }
@@ -96,14 +96,14 @@ __device__ __forceinline__ bool is_orthogonal(const float* R) {  // rotation_mat
       n2 += v * v;
     }
   const float det = R[0] * (R[4] * R[8] - R[7] * R[5]) - R[3] * (R[1] * R[8] - R[7] * R[2]) + R[6] * (R[1] * R[5] - R[4] * R[2]);
-  return __fsqrt_rn(n2) < 1e-5f && det > 0.0f;
+  return sqrtf(n2) < 1e-5f && det > 0.0f;
 }
 
 // Sophus::SE3f::exp(inc) * (q,t)  (se3.hpp:723-745, so3.hpp:531-565, se3.hpp:317-321, so3.hpp:335-352)
 __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, const float* t, float* qo, float* to) {
   const float ox = a[3], oy = a[4], oz = a[5];
   const float theta_sq = ox * ox + oy * oy + oz * oz;
-  const float theta = __fsqrt_rn(theta_sq);
+  const float theta = sqrtf(theta_sq);
   float imag, real;
   float V[9];  // row-major 3x3
   const float O[9] = {0.f, -oz, oy, oz, 0.f, -ox, -oy, ox, 0.f};

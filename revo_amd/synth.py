@@ -202,9 +202,16 @@ def ate_rmse(est, gt):
     return float(np.sqrt((err ** 2).sum(1).mean()))
 
 
+def rot_angle(Ra, Rb):
+    """Angle (rad) of Ra^T Rb via the skew part (|sin| of the angle): accurate for the tiny
+    angles compared here, where arccos((trace-1)/2) has a ~3e-4 rad float32 noise floor."""
+    d = np.asarray(Ra, np.float64).T @ np.asarray(Rb, np.float64)
+    w = 0.5 * np.array([d[2, 1] - d[1, 2], d[0, 2] - d[2, 0], d[1, 0] - d[0, 1]])
+    s = float(np.linalg.norm(w))
+    c = (np.trace(d) - 1.0) / 2.0
+    return float(np.arctan2(s, c)) if s > 1e-3 else s
+
+
 def pose_error(R_est, T_est, T_gt):
     """(rotation error rad, translation error m) of (R,T) vs a 4x4 ground truth."""
-    Rg, tg = T_gt[:3, :3], T_gt[:3, 3]
-    dR = np.asarray(R_est, np.float64).T @ Rg
-    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
-    return float(ang), float(np.linalg.norm(np.asarray(T_est, np.float64) - tg))
+    return rot_angle(R_est, T_gt[:3, :3]), float(np.linalg.norm(np.asarray(T_est, np.float64) - T_gt[:3, 3]))

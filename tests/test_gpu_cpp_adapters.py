@@ -1,0 +1,49 @@
+"""The header-only C++ adapters (revo_amd/cpp/revo_adapters.hpp) drive the same C ABI as the
+Python mirror: a system.cpp-style C++ host must get bit-identical poses."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_adapter_host_matches_python_host(tmp_path):
+    from revo_amd import api, synth
+    from revo_amd.settings import ImgPyramidSettings, TrackerSettings
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    pair = synth.make_pair(11, s)
+    exe = str(tmp_path / "adapter_track")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "adapter_track.cpp"),
+                           "-L" + os.path.join(ROOT, "revo_amd"), "-lrevo_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "revo_amd")])
+    names = []
+    for tag in ("ref", "curr"):
+        for k, ext in ((0, "bgr"), (1, "depth")):
+            p = str(tmp_path / ("%s.%s" % (tag, ext)))
+            np.ascontiguousarray(pair[tag][k]).tofile(p)
+            names.append(p)
+    out = subprocess.check_output([exe, "320", "240"] + names, timeout=120).decode()
+    vals = {ln.split()[0]: ln.split()[1:] for ln in out.strip().splitlines()}
+    R_cpp = np.array(vals["R"], np.float32).reshape(3, 3).T
+    T_cpp = np.array(vals["T"], np.float32)
+
+    cam = api.CameraPyr(s)
+    trk = api.TrackerNew(TrackerSettings(), s, cam)
+    ref = api.ImgPyramidRGBD(s, cam, *pair["ref"])
+    cur = api.ImgPyramidRGBD(s, cam, *pair["curr"], timestamp=1.0 / 30)
+    ref.makeKeyframe()
+    trk.addOldPclAndPose(ref, trk.histogramLevel, np.eye(4), 0.0)
+    st, R, T, err = trk.trackFrames(np.eye(3), np.zeros(3), ref, cur)
+    M = np.eye(4, dtype=np.float32)
+    M[:3, :3], M[:3, 3] = R, T
+    st2 = trk.assessTrackingQuality(M, cur)
+    assert np.array_equal(R_cpp, R) and np.array_equal(T_cpp, T)
+    assert np.float32(vals["err"][0]) == np.float32(err)
+    assert int(vals["status"][0]) == st2
+    assert int(vals["n0"][0]) == cur.return3DEdges(0).shape[0]
+    assert vals["notkf"] == ["error"]
+    er, et = synth.pose_error(R_cpp, T_cpp, pair["T_ref_curr"])
+    assert er < 3e-3 and et < 5e-3

@@ -166,9 +166,7 @@ def _setup_pair(api, ro, s, pair, trk_settings=None):
     return cam, g_ref, g_cur, o_ref, o_cur, gt, ot
 
 
-def rot_angle(Ra, Rb):
-    d = np.asarray(Ra, np.float64).T @ np.asarray(Rb, np.float64)
-    return float(np.arccos(np.clip((np.trace(d) - 1) / 2, -1, 1)))
+rot_angle = synth.rot_angle
 
 
 def test_residual_and_normal_equations_parity(api, ro, pair640):
