@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--input-cache", default="", help="npz path: load the rendered inputs from it if present, "
+                    "else render and save (profilers deadlock on the forked render pool)")
+    ap.add_argument("--render-procs", type=int, default=0, help="0 = auto")
+    ap.add_argument("--no-overlap", action="store_true", help="single batch, single stream (no build/track overlap)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -60,15 +64,23 @@ def main():
     s = ImgPyramidSettings.scaled(a.width, a.height, a.levels, hist_patch=hist)
     seeds = [rank * a.pairs + i for i in range(a.pairs)]
     jobs = [(sd, a.width, a.height, a.levels) for sd in seeds]
-    nproc = max(1, min(16, (os.cpu_count() or 1) // max(1, world), a.pairs))
+    nproc = a.render_procs or max(1, min(16, (os.cpu_count() or 1) // max(1, world), a.pairs))
     t0 = time.time()
-    if nproc > 1:
+    cache = a.input_cache and ("%s.r%d.npz" % (a.input_cache, rank))
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        rendered = [(z["rb"][i], z["rd"][i], z["cb"][i], z["cd"][i], z["gt"][i]) for i in range(a.pairs)]
+    elif nproc > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:
             rendered = pool.map(render_pair, jobs)
     else:
         rendered = [render_pair(j) for j in jobs]
     t_render = time.time() - t0
+    if cache and not os.path.exists(cache):
+        np.savez(cache, rb=np.stack([r[0] for r in rendered]), rd=np.stack([r[1] for r in rendered]),
+                 cb=np.stack([r[2] for r in rendered]), cd=np.stack([r[3] for r in rendered]),
+                 gt=np.stack([r[4] for r in rendered]))
     bgr = np.stack([r[k] for r in rendered for k in (0, 2)])
     dep = np.stack([r[k] for r in rendered for k in (1, 3)])
     gt = [r[4] for r in rendered]
@@ -84,22 +96,40 @@ def main():
     from revo_amd import api, synth
     cam = api.CameraPyr(s, device=local_rank)
     api.TrackerNew(TrackerSettings(), s, cam)
-    bt = api.BatchTracker(cam, a.pairs)
+    # Two batches, two streams: the pyramid build of step k+1 (streaming, all CUs) overlaps the
+    # tracker of step k (192 latency-bound workgroups).  Trackers serialise on one stream,
+    # builds on the other; events hand each batch back and forth.
+    nbuf = 1 if a.no_overlap else 2
+    bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf)]
+    bt = bts[0]
     d_bgr = torch.from_numpy(bgr).to(dev)
     d_dep = torch.from_numpy(dep).to(dev)
-    d_res = torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev)
+    d_ress = [torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    d_res = d_ress[0]
     d_all = torch.zeros(world * a.pairs * 96, dtype=torch.uint8, device=dev) if world > 1 else None
-    # an explicit (non-null) torch stream: the HIP kernels, torch's events and the RCCL
-    # collective are all ordered on it
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream != 0
+    s_track = torch.cuda.Stream(device=dev)   # also carries the RCCL collective
+    s_build = torch.cuda.Stream(device=dev) if nbuf == 2 else s_track
+    torch.cuda.set_stream(s_track)
+    stream = s_track.cuda_stream
+    assert stream != 0 and s_build.cuda_stream != 0
+    ev_built = [torch.cuda.Event() for _ in range(nbuf)]
+    ev_tracked = [torch.cuda.Event() for _ in range(nbuf)]
+    counter = [0]
 
     def step():
-        bt.track(d_bgr.data_ptr(), d_dep.data_ptr(), d_res.data_ptr(), stream=stream)
+        k = counter[0] % nbuf
+        counter[0] += 1
+        if nbuf == 2:
+            s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
+            bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=s_build.cuda_stream)
+            ev_built[k].record(s_build)
+            s_track.wait_event(ev_built[k])
+            bts[k].track_only(d_ress[k].data_ptr(), stream=s_track.cuda_stream)
+        else:
+            bts[k].track(d_bgr.data_ptr(), d_dep.data_ptr(), d_ress[k].data_ptr(), stream=stream)
         if world > 1:  # the only collective: 96 B x pairs per rank, RCCL over xGMI
-            dist.all_gather_into_tensor(d_all, d_res)
+            dist.all_gather_into_tensor(d_all, d_ress[k])
+        ev_tracked[k].record(s_track)
 
     for _ in range(a.warmup):
         step()
@@ -119,6 +149,8 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    d_res = d_ress[(counter[0] - 1) % nbuf]
+    bt = bts[(counter[0] - 1) % nbuf]
 
     # ---- correctness of what was timed (never skipped work): poses vs ground truth
     res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), a.pairs)
@@ -173,6 +205,7 @@ def main():
                         % (a.width, a.height, a.levels, a.pairs, 2 if world == 1 else 4),
             "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
             "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
+            "pipelining": "none" if a.no_overlap else "double-buffered: build of step k+1 overlaps tracker of step k",
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -183,6 +216,7 @@ def main():
         "pose_error_vs_ground_truth": {"rot_rad_median": rot_med, "trans_m_median": tr_med},
         "mean_edge_points_lvl0": float(npts[:, 0].mean()),
         "mean_evals_per_level": [float(x) for x in evals.mean(0)],
+        "evals_raw_mean": [float(x) for x in np.array([r["evals"] for r in res], np.float64).mean(0)],
         "input_render_s": t_render,
     }
 

@@ -62,8 +62,7 @@ struct FramePlanes {
 struct PairDesc {
   const float4* pts[REVO_L];    // current frame's 3-D edge lists
   const int* npts;              // -> int[REVO_L] of the current frame
-  const float4* table[REVO_L];  // keyframe's gradient/DT table
-  const float* dt_coarse;       // keyframe's DT at pyr_min_lvl (init check)
+  const float* dt[REVO_L];      // keyframe's distance transform (gradients are formed on the fly)
   float R[9];                   // initial R (column-major), curr -> ref
   float T[3];
 };
@@ -95,7 +94,8 @@ struct EvalOut {
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
 #define NMS_TILE_W 64
 #define NMS_TILE_H 16
-#define TRACK_THREADS 1024
+#define TRACK_THREADS 512
+#define TRACK_MAX_CLUSTER 8
 
 // ---- launchers (defined in the kernel translation units) -------------------
 void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,
@@ -108,7 +108,9 @@ void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s
 // keyframe promotion of frames f0, f0+fstride, ... (count frames)
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
-                  int n_pairs, hipStream_t s);
+                  int n_pairs, unsigned long long* d_mail, int cluster, hipStream_t s);
+int track_blocks_per_cu();  // occupancy query of k_track (advisory)
+void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
 void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds,
                  const float4* const* d_cloud_pts, const int* const* d_cloud_n, const float* d_RT /*n x 12*/,
                  int* d_marks /*npix*/, int* d_hist8 /*hist[4], overlaps[4]*/, int use_orig_edges, hipStream_t s);

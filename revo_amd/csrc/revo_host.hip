@@ -84,6 +84,8 @@ struct revo_ctx {
   PairDesc* h_desc; PairDesc* d_desc;
   revo_pair_result* h_res; revo_pair_result* d_res;
   EvalOut* h_eval; EvalOut* d_eval;
+  unsigned long long* d_mail;   // cluster mailbox of the single-pair path
+  int num_cus, blocks_per_cu;
   // vote
   std::deque<Past> past;
   int* d_marks; int* d_hist8; int* h_hist8;
@@ -98,6 +100,7 @@ struct revo_pyr {
   bool owns_fs;
   bool is_kf;
   double ts;
+  bool table_built;
 };
 
 struct revo_batch {
@@ -106,8 +109,10 @@ struct revo_batch {
   FrameSet* fs;
   std::vector<revo_pyr> views;
   PairDesc* h_descs; PairDesc* d_descs;
+  unsigned long long* d_mail;
+  int cluster;
   hipStream_t stream;
-  hipEvent_t ev0, ev1;
+  hipEvent_t ev0, ev1, ev_upload;
 };
 
 // ---------------------------------------------------------------- geometry --
@@ -140,6 +145,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
       v.w = (int)((float)s.width * scale); v.h = (int)((float)s.height * scale);
     }
     v.npix = v.w * v.h;
+    if (v.npix % 16) { *why = "every level must have a multiple of 16 pixels"; return -1; }
     v.patch = s.hist_patch[l] > 0 ? s.hist_patch[l] : 0;
     if (v.patch > 0) {
       v.hist_w = v.w / v.patch; v.hist_h = v.h / v.patch;
@@ -175,6 +181,22 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
     t->cam[l].fx = v.fx; t->cam[l].fy = v.fy; t->cam[l].cx = v.cx; t->cam[l].cy = v.cy; t->cam[l].w = v.w; t->cam[l].h = v.h;
   }
 }
+
+// Workgroups per frame-pair.  Every member of every cluster must be resident at once (they
+// exchange partial sums inside the launch), so the grid stays at <= 75 % of what the device
+// can hold for this kernel; the in-kernel wait is bounded as a second line of defence.
+static int pick_cluster(const revo_ctx* c, int n_pairs) {
+  const int resident = c->num_cus * c->blocks_per_cu;
+  int cl = (int)(0.75 * resident) / std::max(1, n_pairs);
+  if (cl > TRACK_MAX_CLUSTER) cl = TRACK_MAX_CLUSTER;
+  if (const char* e = getenv("REVO_TRACK_CLUSTER")) {  // tuning knob, clamped to what fits
+    const int want = atoi(e);
+    if (want >= 1 && want < cl) cl = want;
+  }
+  if (cl < 1) cl = 1;
+  return cl;
+}
+static size_t mail_bytes(int n_pairs, int cluster) { return sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32; }
 
 // --------------------------------------------------------------- FrameSets --
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -265,6 +287,11 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipMalloc((void**)&c->d_res, sizeof(revo_pair_result)));
   HIPCHECK(hipHostMalloc((void**)&c->h_eval, sizeof(EvalOut)));
   HIPCHECK(hipMalloc((void**)&c->d_eval, sizeof(EvalOut)));
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount;
+  c->blocks_per_cu = std::min(track_blocks_per_cu(), 2);
+  HIPCHECK(hipMalloc((void**)&c->d_mail, mail_bytes(1, TRACK_MAX_CLUSTER)));
   size_t maxpix = 0;
   for (int l = 0; l < c->geom.n_levels; ++l) maxpix = std::max(maxpix, (size_t)c->geom.lv[l].npix);
   HIPCHECK(hipMalloc((void**)&c->d_marks, sizeof(int) * maxpix));
@@ -287,7 +314,7 @@ extern "C" void revo_ctx_destroy(revo_ctx* c) {
   for (auto& p : c->past) { hipFree(p.d_pts); hipFree(p.d_n); }
   for (FrameSet* fs : c->pool) frameset_destroy(fs);
   hipHostFree(c->h_desc); hipFree(c->d_desc); hipHostFree(c->h_res); hipFree(c->d_res);
-  hipHostFree(c->h_eval); hipFree(c->d_eval);
+  hipHostFree(c->h_eval); hipFree(c->d_eval); hipFree(c->d_mail);
   hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8);
   hipFree(c->d_cloud_pts); hipFree(c->d_cloud_n); hipFree(c->d_RT);
   hipHostFree(c->h_cloud_pts); hipHostFree(c->h_cloud_n); hipHostFree(c->h_RT);
@@ -339,7 +366,7 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha,
                 c->stream);
   HIPCHECK(hipGetLastError());
-  revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts};
+  revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts, false};
   *out = p;
   return REVO_OK;
 }
@@ -370,6 +397,7 @@ extern "C" int revo_pyramid_make_keyframe(revo_pyr* p) {
   launch_keyframe(p->ctx->geom, p->fs->p, p->frame, 1, 1, p->ctx->stream);
   HIPCHECK(hipGetLastError());
   p->is_kf = true;
+  p->table_built = false;
   return REVO_OK;
 }
 extern "C" int revo_pyramid_is_keyframe(const revo_pyr* p) { return p && p->is_kf; }
@@ -398,6 +426,12 @@ extern "C" int revo_pyramid_read(revo_pyr* p, revo_plane what, int lvl, void* ds
       src = P.dt[lvl] + f * v.npix; esz = 4; break;
     case REVO_PLANE_GRADTABLE:
       if (!p->is_kf) return fail(REVO_ERR_NOT_KEYFRAME, "optimizationStructure not built");
+      if (!p->table_built) {  // lazily materialised: the tracker itself samples the DT plane
+        launch_grad_table(c->geom, P, p->frame, 1, 1, c->stream);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        p->table_built = true;
+      }
       src = P.table[lvl] + f * v.npix; esz = 16; break;
     case REVO_PLANE_EDGES3D: {
       int np = 0;
@@ -423,11 +457,9 @@ static void fill_desc(PairDesc* d, const revo_pyr* ref, const revo_pyr* curr, co
   memset(d, 0, sizeof(*d));
   for (int l = 0; l < g.n_levels; ++l) {
     d->pts[l] = curr->fs->p.pts[l] + (size_t)curr->frame * g.lv[l].npix;
-    d->table[l] = ref->fs->p.table[l] + (size_t)ref->frame * g.lv[l].npix;
+    d->dt[l] = ref->fs->p.dt[l] + (size_t)ref->frame * g.lv[l].npix;
   }
   d->npts = curr->fs->p.npts + (size_t)curr->frame * REVO_L;
-  const int cl = ref->ctx->ps.pyr_min_lvl;
-  d->dt_coarse = ref->fs->p.dt[cl] + (size_t)ref->frame * g.lv[cl].npix;
   if (R) memcpy(d->R, R, sizeof(float) * 9); else { d->R[0] = d->R[4] = d->R[8] = 1.f; }
   if (T) memcpy(d->T, T, sizeof(float) * 3);
 }
@@ -443,7 +475,7 @@ static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, co
                       const TrackParams& tp) {
   fill_desc(c->h_desc, ref, curr, R, T);
   HIPCHECK(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PairDesc), hipMemcpyHostToDevice, c->stream));
-  launch_track(c->d_desc, tp, c->d_res, c->d_eval, 1, c->stream);
+  launch_track(c->d_desc, tp, c->d_res, c->d_eval, 1, c->d_mail, pick_cluster(c, 1), c->stream);
   HIPCHECK(hipGetLastError());
   if (tp.eval_only) HIPCHECK(hipMemcpyAsync(c->h_eval, c->d_eval, sizeof(EvalOut), hipMemcpyDeviceToHost, c->stream));
   else HIPCHECK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(revo_pair_result), hipMemcpyDeviceToHost, c->stream));
@@ -635,7 +667,10 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   if (rc) { delete b; return rc; }
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
-  for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0});
+  HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
+  b->cluster = pick_cluster(c, n_pairs);
+  HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
+  for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false});
   HIPCHECK(hipHostMalloc((void**)&b->h_descs, sizeof(PairDesc) * n_pairs));
   HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
   for (int i = 0; i < n_pairs; ++i) fill_desc(&b->h_descs[i], &b->views[2 * i], &b->views[2 * i + 1], nullptr, nullptr);
@@ -647,8 +682,8 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->stream);
-  hipHostFree(b->h_descs); hipFree(b->d_descs);
-  hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+  hipHostFree(b->h_descs); hipFree(b->d_descs); hipFree(b->d_mail);
+  hipEventDestroy(b->ev0); hipEventDestroy(b->ev1); hipEventDestroy(b->ev_upload);
   hipStreamDestroy(b->stream);
   frameset_destroy(b->fs);
   delete b;
@@ -661,16 +696,20 @@ extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float
   enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s);
   launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
   HIPCHECK(hipGetLastError());
+  for (auto& v : b->views) v.table_built = false;
   return REVO_OK;
 }
 
 static int batch_upload_init(revo_batch* b, const float* h_init_RT, hipStream_t s) {
+  // the previous upload reads h_descs asynchronously: let it finish before rewriting the poses
+  HIPCHECK(hipEventSynchronize(b->ev_upload));
   for (int i = 0; i < b->n_pairs; ++i) {
     PairDesc& d = b->h_descs[i];
     if (h_init_RT) { memcpy(d.R, h_init_RT + 12 * i, sizeof(float) * 9); memcpy(d.T, h_init_RT + 12 * i + 9, sizeof(float) * 3); }
     else { memset(d.R, 0, sizeof(d.R)); d.R[0] = d.R[4] = d.R[8] = 1.f; memset(d.T, 0, sizeof(d.T)); }
   }
   HIPCHECK(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipEventRecord(b->ev_upload, s));
   return REVO_OK;
 }
 
@@ -682,7 +721,7 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
-  launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, s);
+  launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, b->cluster, s);
   HIPCHECK(hipGetLastError());
   return REVO_OK;
 }
@@ -719,7 +758,7 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
-    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, s);
+    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, b->cluster, s);
     HIPCHECK(hipEventRecord(b->ev1, s));
     HIPCHECK(hipEventSynchronize(b->ev1));
     float ms = 0.f;

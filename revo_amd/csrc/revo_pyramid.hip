@@ -116,13 +116,45 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
 // parent of a pixel always has a smaller key, roots point to themselves.
 // Lock-free union by atomicMin (Komura-style); placement/order independent.
 // ---------------------------------------------------------------------------
+// Loads that race with concurrent unions: agent scope is enough (L2-served); HIP's bare
+// __atomic_load_n would be SYSTEM scope, i.e. a cache-bypassing fabric read per hop.
 template <typename P>
-__device__ __forceinline__ int uf_load(P* L, int i) { return __atomic_load_n(&L[i], __ATOMIC_RELAXED); }
+__device__ __forceinline__ int uf_load(P* L, int i) { return __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <typename P>
 __device__ __forceinline__ int uf_find(P* L, int x) {
   int p = uf_load(L, x);
   while (p != x) { x = p; p = uf_load(L, x); }
+  return x;
+}
+// Global variant with path halving: x's parent is replaced by its grandparent through
+// atomicMin (parents only ever decrease, and a grandparent is in the same set), which keeps
+// the root chains of giant components (textured walls) short while unions are in flight.
+__device__ __forceinline__ int uf_find_halving(int* L, int x) {
+  int p = uf_load(L, x);
+  while (p != x) {
+    const int gp = uf_load(L, p);
+    if (gp != p) atomicMin(&L[x], gp);
+    x = p;
+    p = gp;
+  }
+  return x;
+}
+__device__ __forceinline__ void uf_unite_global(int* L, int a, int b) {
+  for (;;) {
+    a = uf_find_halving(L, a);
+    b = uf_find_halving(L, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(&L[b], a);
+    if (old == b) return;
+    b = old;
+  }
+}
+// After a kernel boundary the forest is final: plain (cacheable) loads.
+__device__ __forceinline__ int uf_find_final(const int* __restrict__ L, int x) {
+  int p = L[x];
+  while (p != x) { x = p; p = L[x]; }
   return x;
 }
 template <typename P>
@@ -185,7 +217,6 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
 
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
   const int lx0 = (tid % 16) * 4, ly = tid / 16;
-  uint32_t packed = 0;
   int cand[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -214,7 +245,6 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     const bool inside = (x0 + lx < w) && (y0 + ly < h);
     if (!inside) val = 0;
     cand[k] = val;
-    packed |= (uint32_t)val << (8 * k);
     s_lab[ly * NMS_TILE_W + lx] = val ? ly * NMS_TILE_W + lx : -1;
   }
   __syncthreads();
@@ -232,80 +262,129 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     }
   }
   __syncthreads();
+  // tile-local roots; a strong pixel marks its tile root (s_mag is free now: reuse row 0.. as flags)
+  int* s_strong = &s_mag[0][0];  // (NMS_TILE_H+2)*(NMS_TILE_W+3) ints >= NMS_TILE_H*NMS_TILE_W
+  int root[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    root[k] = cand[k] ? uf_find(s_lab, ly * NMS_TILE_W + lx0 + k) : -1;
+    s_strong[ly * NMS_TILE_W + lx0 + k] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (cand[k] == 2) s_strong[root[k]] = 1;  // benign same-value race
+  __syncthreads();
   if (x0 + lx0 < w && y0 + ly < h) {
     const size_t pix = (size_t)(y0 + ly) * w + x0 + lx0;
-    *reinterpret_cast<uint32_t*>(pl.nms[l] + (size_t)f * lv.npix + pix) = packed;
+    uint32_t packed = 0;
     int4 lab;
     int* lp = &lab.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int key = -1;
+      uint32_t byte = (uint32_t)cand[k];  // 0 none, 1 weak, 2 strong
       if (cand[k]) {
-        const int r = uf_find(s_lab, ly * NMS_TILE_W + lx0 + k);
+        const int me = ly * NMS_TILE_W + lx0 + k;
+        const int r = root[k];
         key = (y0 + r / NMS_TILE_W) * w + x0 + (r % NMS_TILE_W);
+        if (r == me) byte |= 8u | (s_strong[me] ? 4u : 0u);  // bit 3: tile root, bit 2: its component holds a strong pixel
       }
       lp[k] = key;
+      packed |= byte << (8 * k);
     }
+    *reinterpret_cast<uint32_t*>(pl.nms[l] + (size_t)f * lv.npix + pix) = packed;
     *reinterpret_cast<int4*>(pl.scratch[l] + (size_t)f * lv.npix + pix) = lab;
   }
+}
+
+// The three global hysteresis passes handle 16 pixels per thread (one 16-byte load of the
+// map): with one byte per thread they were pure launch/latency overhead (26 M threads).
+// level = blockIdx.y (block-uniform, so the geometry is read with scalar loads); blocks past
+// the end of a small level exit at once.
+__device__ __forceinline__ bool ccl_chunk(const PyrGeom& g, int chunk, int* l_out, int* p0_out) {
+  const int l = blockIdx.y;
+  if (chunk * 16 >= g.lv[l].npix) return false;
+  *l_out = l;
+  *p0_out = chunk * 16;
+  return true;
 }
 
 // a5 (second half, 1/3): unite candidates across tile borders (global memory).
 __global__ void __launch_bounds__(256) k_ccl_border(PyrGeom g, FramePlanes pl) {
   const int f = blockIdx.z;
-  const int gi = blockIdx.x * 256 + threadIdx.x;
-  if (gi >= g.total_pix) return;
-  const int l = level_of(g, gi, &LevelGeom::pix_base);
-  const LevelGeom lv = g.lv[l];
-  const int p = gi - lv.pix_base;
+  int l, p0;
+  if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
+  const LevelGeom& lv = g.lv[l];
   const int w = lv.w;
-  const int x = p % w, y = p / w;
-  const int lx = x % NMS_TILE_W, lyy = y % NMS_TILE_H;
-  if (lx != 0 && lyy != 0 && lx != NMS_TILE_W - 1) return;
+  const uint4 m4 = *reinterpret_cast<const uint4*>(pl.nms[l] + (size_t)f * lv.npix + p0);
+  if ((m4.x | m4.y | m4.z | m4.w) == 0) return;
   int* L = pl.scratch[l] + (size_t)f * lv.npix;
-  if (L[p] < 0) return;
-  // neighbours that live in another tile
-  if (lx == 0 && x > 0 && L[p - 1] >= 0) uf_unite(L, p, p - 1);
-  if (y > 0) {
-    if ((lx == 0 || lyy == 0) && x > 0 && L[p - w - 1] >= 0) uf_unite(L, p, p - w - 1);
-    if (lyy == 0 && L[p - w] >= 0) uf_unite(L, p, p - w);
-    if ((lx == NMS_TILE_W - 1 || lyy == 0) && x < w - 1 && L[p - w + 1] >= 0) uf_unite(L, p, p - w + 1);
+  const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (((mw[k >> 2] >> (8 * (k & 3))) & 3) == 0) continue;
+    const int p = p0 + k;
+    const int x = p % w, y = p / w;
+    const int lx = x % NMS_TILE_W, lyy = y % NMS_TILE_H;
+    if (lx != 0 && lyy != 0 && lx != NMS_TILE_W - 1) continue;
+    // neighbours that live in another tile
+    if (lx == 0 && x > 0 && L[p - 1] >= 0) uf_unite_global(L, p, p - 1);
+    if (y > 0) {
+      if ((lx == 0 || lyy == 0) && x > 0 && L[p - w - 1] >= 0) uf_unite_global(L, p, p - w - 1);
+      if (lyy == 0 && L[p - w] >= 0) uf_unite_global(L, p, p - w);
+      if ((lx == NMS_TILE_W - 1 || lyy == 0) && x < w - 1 && L[p - w + 1] >= 0) uf_unite_global(L, p, p - w + 1);
+    }
   }
 }
 
-// a5 (2/3): every strong pixel marks the root of its component (bit 2 of the map).
+// a5 (2/3): only TILE ROOTS (bit 3) work here: each is re-pointed straight at its global
+// root (so every pixel is <= 2 hops away afterwards) and hands its tile-level "holds a
+// strong pixel" bit to that root.
 __global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
   const int f = blockIdx.z;
-  const int gi = blockIdx.x * 256 + threadIdx.x;
-  if (gi >= g.total_pix) return;
-  const int l = level_of(g, gi, &LevelGeom::pix_base);
-  const LevelGeom lv = g.lv[l];
-  const int p = gi - lv.pix_base;
+  int l, p0;
+  if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
+  const LevelGeom& lv = g.lv[l];
   uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
-  if ((nms[p] & 3) != 2) return;
+  const uint4 m4 = *reinterpret_cast<const uint4*>(nms + p0);
+  if (((m4.x | m4.y | m4.z | m4.w) & 0x08080808u) == 0) return;
+  const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
   int* L = pl.scratch[l] + (size_t)f * lv.npix;
-  const int r = uf_find(L, p);
-  nms[r] = (uint8_t)((nms[r] & 3) | 4);  // all writers store the same value
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t b = (mw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+    if (!(b & 8u)) continue;
+    const int p = p0 + k;
+    const int r = uf_find_final(L, p);
+    if (r != p) L[p] = r;  // any concurrent reader sees the old parent or the root: both are ancestors
+    if (b & 4u) nms[r] = (uint8_t)(nms[r] | 4u);  // every writer sets bit 2, the other bits are constant
+  }
 }
 
 // a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes
 // edgesPyr and its clone edgesOrigPyr (imgpyramidrgbd.cpp:185-186).
 __global__ void __launch_bounds__(256) k_ccl_out(PyrGeom g, FramePlanes pl) {
   const int f = blockIdx.z;
-  const int gi = blockIdx.x * 256 + threadIdx.x;
-  if (gi >= g.total_pix) return;
-  const int l = level_of(g, gi, &LevelGeom::pix_base);
-  const LevelGeom lv = g.lv[l];
-  const int p = gi - lv.pix_base;
+  int l, p0;
+  if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
+  const LevelGeom& lv = g.lv[l];
   const uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
-  uint8_t e = 0;
-  if (nms[p] & 3) {
-    int* L = pl.scratch[l] + (size_t)f * lv.npix;
-    const int r = uf_find(L, p);
-    e = (nms[r] & 4) ? 255 : 0;
+  const uint4 m4 = *reinterpret_cast<const uint4*>(nms + p0);
+  uint32_t ow[4] = {0u, 0u, 0u, 0u};
+  if ((m4.x | m4.y | m4.z | m4.w) & 0x03030303u) {
+    const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
+    const int* L = pl.scratch[l] + (size_t)f * lv.npix;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (((mw[k >> 2] >> (8 * (k & 3))) & 3) == 0) continue;
+      const int r = uf_find_final(L, p0 + k);
+      if (nms[r] & 4) ow[k >> 2] |= 0xffu << (8 * (k & 3));
+    }
   }
-  pl.edges[l][(size_t)f * lv.npix + p] = e;
-  pl.edges_orig[l][(size_t)f * lv.npix + p] = e;
+  const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  *reinterpret_cast<uint4*>(pl.edges[l] + (size_t)f * lv.npix + p0) = o;
+  *reinterpret_cast<uint4*>(pl.edges_orig[l] + (size_t)f * lv.npix + p0) = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -389,11 +468,10 @@ __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
 template <bool WRITE>
 __global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl) {
   const int f = blockIdx.z;
-  const int gi = blockIdx.x * 256 + threadIdx.x;
-  if (gi >= g.total_cc) return;
-  const int l = level_of(g, gi, &LevelGeom::cc_base);
-  const LevelGeom lv = g.lv[l];
-  const int i = gi - lv.cc_base;
+  const int l = blockIdx.y;  // block-uniform level
+  const LevelGeom& lv = g.lv[l];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= lv.w * lv.nchunk) return;
   const int x = i % lv.w, c = i / lv.w;  // adjacent threads walk adjacent columns
   const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
   const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
@@ -453,24 +531,50 @@ __global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl
 // to OpenCV's (all d2 < 2^24); no edge at all -> OpenCV's 1e15f sentinel.
 // ---------------------------------------------------------------------------
 #define EDT_INF (1 << 29)
-__global__ void __launch_bounds__(128) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+#define EDT_STRIP 64   // columns per block
+#define EDT_GROUPS 16  // row groups per column -> 64 x 16 = 1024 threads, chains of h/16 rows
+__global__ void __launch_bounds__(EDT_STRIP * EDT_GROUPS) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+  __shared__ int s_first[EDT_GROUPS][EDT_STRIP];  // first edge row of the group's segment (or +INF)
+  __shared__ int s_last[EDT_GROUPS][EDT_STRIP];   // last edge row of the segment (or -INF)
   const int f = f0 + blockIdx.z * fstride;
-  const int gi = blockIdx.x * 128 + threadIdx.x;
-  if (gi >= g.total_cols) return;
-  const int l = level_of(g, gi, &LevelGeom::col_base);
+  // decode (level, strip)
+  int l = 0, sidx = blockIdx.x;
+  for (int k = 0; k < g.n_levels; ++k) {
+    const int ns = (g.lv[k].w + EDT_STRIP - 1) / EDT_STRIP;
+    if (sidx < ns) { l = k; break; }
+    sidx -= ns;
+  }
   const LevelGeom lv = g.lv[l];
-  const int x = gi - lv.col_base;
+  const int col = threadIdx.x % EDT_STRIP, grp = threadIdx.x / EDT_STRIP;
+  const int x = sidx * EDT_STRIP + col;
+  const int rpg = (lv.h + EDT_GROUPS - 1) / EDT_GROUPS;
+  const int yb = min(lv.h, grp * rpg), ye = min(lv.h, yb + rpg);
+  const bool in = x < lv.w;
   const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
   int* g2 = pl.scratch[l] + (size_t)f * lv.npix;
-  int d = EDT_INF;
-  for (int y = 0; y < lv.h; ++y) {
-    d = edges[(size_t)y * lv.w + x] ? 0 : (d < EDT_INF ? d + 1 : EDT_INF);
-    g2[(size_t)y * lv.w + x] = d;
+  int first = EDT_INF, last = -EDT_INF;
+  if (in)
+    for (int y = yb; y < ye; ++y)
+      if (edges[(size_t)y * lv.w + x]) { first = min(first, y); last = y; }
+  s_first[grp][col] = first;
+  s_last[grp][col] = last;
+  __syncthreads();
+  if (!in) return;
+  int above = -EDT_INF, below = EDT_INF;  // nearest edge rows outside this segment
+  for (int k = 0; k < grp; ++k) above = max(above, s_last[k][col]);
+  for (int k = EDT_GROUPS - 1; k > grp; --k) below = min(below, s_first[k][col]);
+  // downward walk: distance to the nearest edge at or above y
+  int up = above;
+  for (int y = yb; y < ye; ++y) {
+    if (edges[(size_t)y * lv.w + x]) up = y;
+    g2[(size_t)y * lv.w + x] = (up <= -EDT_INF) ? EDT_INF : (y - up);
   }
-  d = EDT_INF;
-  for (int y = lv.h - 1; y >= 0; --y) {
-    d = edges[(size_t)y * lv.w + x] ? 0 : (d < EDT_INF ? d + 1 : EDT_INF);
-    const int m = min(d, g2[(size_t)y * lv.w + x]);
+  // upward walk: combine with the nearest edge at or below y, square
+  int dn = below;
+  for (int y = ye - 1; y >= yb; --y) {
+    if (edges[(size_t)y * lv.w + x]) dn = y;
+    const int d_dn = (dn >= EDT_INF) ? EDT_INF : (dn - y);
+    const int m = min(d_dn, g2[(size_t)y * lv.w + x]);
     g2[(size_t)y * lv.w + x] = m >= EDT_INF ? EDT_INF : m * m;
   }
 }
@@ -503,11 +607,10 @@ __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int
 // over [w, w*(h-1)), (0.5(prev-next), 0.5(up-down), dt, 0); rows 0 and h-1 zero.
 __global__ void __launch_bounds__(256) k_grad_table(PyrGeom g, FramePlanes pl, int f0, int fstride) {
   const int f = f0 + blockIdx.z * fstride;
-  const int gi = blockIdx.x * 256 + threadIdx.x;
-  if (gi >= g.total_pix) return;
-  const int l = level_of(g, gi, &LevelGeom::pix_base);
-  const LevelGeom lv = g.lv[l];
-  const int i = gi - lv.pix_base;
+  const int l = blockIdx.y;
+  const LevelGeom& lv = g.lv[l];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= lv.npix) return;
   const float* dt = pl.dt[l] + (size_t)f * lv.npix;
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i >= lv.w && i < lv.w * (lv.h - 1)) {
@@ -581,7 +684,7 @@ void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 }
 
 void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  dim3 grid((g.total_pix + 255) / 256, 1, B);
+  dim3 grid((g.lv[0].npix / 16 + 255) / 256, g.n_levels, B);
   hipLaunchKernelGGL(k_ccl_border, grid, dim3(256), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_out, grid, dim3(256), 0, s, g, p);
@@ -598,16 +701,23 @@ void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  dim3 grid((g.total_cc + 255) / 256, 1, B);
+  dim3 grid((g.lv[0].w * g.lv[0].nchunk + 255) / 256, g.n_levels, B);
   hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(256), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels, 1, B), dim3(1024), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(256), 0, s, g, p);
 }
 
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {
-  hipLaunchKernelGGL(k_edt_cols, dim3((g.total_cols + 127) / 128, 1, count), dim3(128), 0, s, g, p, f0, fstride);
+  int strips = 0;
+  for (int l = 0; l < g.n_levels; ++l) strips += (g.lv[l].w + EDT_STRIP - 1) / EDT_STRIP;
+  hipLaunchKernelGGL(k_edt_cols, dim3(strips, 1, count), dim3(EDT_STRIP * EDT_GROUPS), 0, s, g, p, f0, fstride);
   hipLaunchKernelGGL(k_edt_rows, dim3(g.total_rows, 1, count), dim3(256), 0, s, g, p, f0, fstride);
-  hipLaunchKernelGGL(k_grad_table, dim3((g.total_pix + 255) / 256, 1, count), dim3(256), 0, s, g, p, f0, fstride);
+}
+
+// The float4 table is only materialised for the returnOptimizationStructure accessor: the
+// tracker samples the DT plane and forms the same gradients on the fly.
+void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {
+  hipLaunchKernelGGL(k_grad_table, dim3((g.lv[0].npix + 255) / 256, g.n_levels, count), dim3(256), 0, s, g, p, f0, fstride);
 }
 
 void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds,

@@ -5,9 +5,13 @@
 // (optimizer.cpp:235-311), calcErrorAndBuffers + calculateWarpUpdate
 // (optimizer.cpp:74-234) and LGS6 (LGSX.h:185-404).
 //
-// One 1024-thread workgroup per frame-pair runs every pyramid level and every
-// Levenberg-Marquardt iteration on the device: no host round trip between
-// residual evaluations.  The reference's two hot loops (A: warp/project/bilinear
+// A CLUSTER of 512-thread workgroups per frame-pair (8 at batch 32, so all 256 CUs
+// gather) runs every pyramid level and every Levenberg-Marquardt iteration on the
+// device: no host round trip between residual evaluations.  The members of a cluster
+// split the point list, all-gather their 32 partial sums through 8-byte {epoch,value}
+// granules (agent-scope relaxed atomics, the data is the flag; MI355X_MICROARCH.md
+// "handoff" rows) and then take the SAME decision redundantly, so one exchange per
+// evaluation suffices.  Blocks of one pair share blockIdx % 8 (same XCD, same L2).  The reference's two hot loops (A: warp/project/bilinear
 // gather/Huber, B: 6-vector Jacobian into the 6x6 system) are fused, so the 7
 // scratch buffers of optimizer.h:146-152 never exist: each thread keeps the 21
 // upper-triangle entries of J^T W J, the 6 of J^T W r, sum(w r^2), sum(r^2) and
@@ -16,6 +20,13 @@
 // per-wave partials meet in LDS and are summed in double in a fixed order
 // (deterministic run to run), and wave 0 runs the damped 6x6 solve, SE3 exp,
 // and the accept/reject logic, publishing the next pose through LDS.
+//
+// The gradient/DT float4 table of the reference (imgpyramidrgbd.cpp:255-276) is NOT
+// read here: the kernel samples the 4x smaller DT plane and forms the four
+// corner gradients 0.5*(dt[i-1]-dt[i+1]), 0.5*(dt[i-w]-dt[i+w]) on the fly -- the
+// same float operations, hence the same values -- which keeps 4 pairs per XCD inside
+// the 4 MB L2 (first measurements: the table version was gather-latency bound at
+// ~19 cycles/point/CU against ~1.2 cycles of ALU work).
 //
 // There is no dense contraction here (a 6-vector outer product per point), so
 // no MFMA; the kernel is bound by gather latency / L2 bandwidth and by the
@@ -27,6 +38,7 @@ namespace {
 enum { MODE_EVAL = 0, MODE_COST = 1, MODE_DONE = 2 };
 enum { PH_COST_EYE = 0, PH_COST_INIT = 1, PH_LEVEL_FIRST = 2, PH_LM = 3, PH_EVAL_ONLY = 4 };
 #define NWAVES (TRACK_THREADS / 64)
+#define SPIN_LIMIT 400000      // bounded cluster wait (~0.5 s): never hang the GPU
 #define MAX_TOTAL_EVALS 6000  // hang guard; the reference bound is 100 outer iterations x retries
 
 struct Ctrl {  // published by wave 0, read by everyone after the barrier
@@ -45,32 +57,38 @@ struct W0State {  // wave-0 private LM state, kept in LDS to keep VGPRs for the 
   int good, bad;
   float sumw, sumu;
   int evals[REVO_L];
+#ifdef REVO_TRACK_PROFILE
+  long long prof[6];  // cycles: eval loop, barrier 1, LDS sum, cluster exchange, decision, barrier 2
+#endif
 };
 
 // ---- small algebra (Eigen/Sophus semantics, float like the reference) -------
+// Eigen's Quaternionf(Matrix3f): four algebraically equivalent branches chosen by the
+// largest of (trace, m00, m11, m22).  Written branch-free with selects so the quaternion
+// stays in registers (element writes under control flow sent it to scratch memory, i.e. a
+// dozen vector-memory round trips on the serial path of every evaluation).
 __device__ __forceinline__ void quat_from_R(const float* R, float* q) {  // R column-major; q = (w,x,y,z)
 #define RM(r, c) R[(c)*3 + (r)]
-  float t = RM(0, 0) + RM(1, 1) + RM(2, 2);
-  if (t > 0.0f) {
-    t = sqrtf(t + 1.0f);
-    q[0] = 0.5f * t;
-    t = __fdiv_rn(0.5f, t);
-    q[1] = (RM(2, 1) - RM(1, 2)) * t;
-    q[2] = (RM(0, 2) - RM(2, 0)) * t;
-    q[3] = (RM(1, 0) - RM(0, 1)) * t;
-  } else if (RM(0, 0) >= RM(1, 1) && RM(0, 0) >= RM(2, 2)) {  // i = 0
-    t = sqrtf(RM(0, 0) - RM(1, 1) - RM(2, 2) + 1.0f);
-    q[1] = 0.5f * t; t = __fdiv_rn(0.5f, t);
-    q[0] = (RM(2, 1) - RM(1, 2)) * t; q[2] = (RM(1, 0) + RM(0, 1)) * t; q[3] = (RM(2, 0) + RM(0, 2)) * t;
-  } else if (RM(1, 1) > RM(0, 0) && RM(1, 1) >= RM(2, 2)) {  // i = 1
-    t = sqrtf(RM(1, 1) - RM(2, 2) - RM(0, 0) + 1.0f);
-    q[2] = 0.5f * t; t = __fdiv_rn(0.5f, t);
-    q[0] = (RM(0, 2) - RM(2, 0)) * t; q[3] = (RM(2, 1) + RM(1, 2)) * t; q[1] = (RM(0, 1) + RM(1, 0)) * t;
-  } else {  // i = 2
-    t = sqrtf(RM(2, 2) - RM(0, 0) - RM(1, 1) + 1.0f);
-    q[3] = 0.5f * t; t = __fdiv_rn(0.5f, t);
-    q[0] = (RM(1, 0) - RM(0, 1)) * t; q[1] = (RM(0, 2) + RM(2, 0)) * t; q[2] = (RM(1, 2) + RM(2, 1)) * t;
-  }
+  const float m00 = RM(0, 0), m11 = RM(1, 1), m22 = RM(2, 2);
+  const float tr = m00 + m11 + m22;
+  const bool b0 = tr > 0.0f;
+  const bool i1 = m11 > m00;                     // Eigen: i = 0; if (m11 > m00) i = 1; if (m22 > m(i,i)) i = 2;
+  const bool i2 = m22 > (i1 ? m11 : m00);
+  const int sel = b0 ? 0 : (i2 ? 3 : (i1 ? 2 : 1));  // 0: trace, 1: i=0, 2: i=1, 3: i=2
+  const float arg = sel == 0 ? tr + 1.0f
+                  : sel == 1 ? (m00 - m11 - m22 + 1.0f)
+                  : sel == 2 ? (m11 - m22 - m00 + 1.0f)
+                             : (m22 - m00 - m11 + 1.0f);
+  const float t = sqrtf(arg);
+  const float h = 0.5f * t;
+  const float s = __fdiv_rn(0.5f, t);
+  const float d21 = (RM(2, 1) - RM(1, 2)) * s, d02 = (RM(0, 2) - RM(2, 0)) * s, d10 = (RM(1, 0) - RM(0, 1)) * s;
+  const float s10 = (RM(1, 0) + RM(0, 1)) * s, s20 = (RM(2, 0) + RM(0, 2)) * s, s21 = (RM(2, 1) + RM(1, 2)) * s;
+  const float qw = sel == 0 ? h : sel == 1 ? d21 : sel == 2 ? d02 : d10;
+  const float qx = sel == 0 ? d21 : sel == 1 ? h : sel == 2 ? s10 : s20;
+  const float qy = sel == 0 ? d02 : sel == 1 ? s10 : sel == 2 ? h : s21;
+  const float qz = sel == 0 ? d10 : sel == 1 ? s20 : sel == 2 ? s21 : h;
+  q[0] = qw; q[1] = qx; q[2] = qy; q[3] = qz;
 #undef RM
 }
 
@@ -215,14 +233,213 @@ __device__ __forceinline__ void butterfly_step(float* v, int lane) {
   }
 }
 
+// ---- cluster all-gather of the 32 per-workgroup partials -------------------------
+typedef unsigned long long u64;
+// mail layout per pair: [2 (epoch parity)][cluster][32] granules of {epoch<<32 | float bits}
+__device__ __forceinline__ bool cluster_allgather(u64* __restrict__ mail_pair, int cluster, int member, unsigned epoch,
+                                                  float mine, int lane, double* tot_out) {
+  u64* slot = mail_pair + (size_t)(epoch & 1u) * cluster * 32;
+  if (lane < 32)
+    __hip_atomic_store(&slot[member * 32 + lane], ((u64)epoch << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  double tot = 0.0;
+  for (unsigned spins = 0;; ++spins) {
+    bool all = true;
+    tot = 0.0;
+    if (lane < 32) {
+      for (int j = 0; j < cluster; ++j) {
+        const u64 g = __hip_atomic_load(&slot[j * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        all = all && ((unsigned)(g >> 32) == epoch);
+        tot += (double)__uint_as_float((unsigned)g);  // fixed order j = 0..cluster-1: same bits in every member
+      }
+    }
+    if (__all(all)) break;
+    if (spins > SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  *tot_out = tot;
+  return true;
+}
+
+// explicit global address space: the pointers come out of the descriptor (generic), and
+// flat loads would tie up both vmcnt and lgkmcnt
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(1)))* gf32p;
+typedef const f4v __attribute__((address_space(1)))* gf4p;
+
+// 12 DT samples around (ix,iy): rows iy-1 (2), iy (4), iy+1 (4), iy+2 (2)
+struct DtPatch { float a0, a1, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1; };
+template <typename PTR>
+__device__ __forceinline__ DtPatch load_patch(PTR dt, int w, int ix, int iy) {
+  PTR p = dt + iy * w + ix;
+  DtPatch q;
+  q.a0 = p[-w]; q.a1 = p[-w + 1];
+  q.b0 = p[-1]; q.b1 = p[0]; q.b2 = p[1]; q.b3 = p[2];
+  q.c0 = p[w - 1]; q.c1 = p[w]; q.c2 = p[w + 1]; q.c3 = p[w + 2];
+  q.d0 = p[2 * w]; q.d1 = p[2 * w + 1];
+  return q;
+}
+
+struct PtState { float X, Y, Z, dx, dy; int ix, iy; bool valid; };
+
+__device__ __forceinline__ PtState project_point(const f4v p, const float* R, const float* T, float fx, float fy, float cx,
+                                                 float cy, float wlim, float hlim, bool in_range) {
+  PtState s;
+  s.X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
+  s.Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
+  s.Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
+  const float u = __fdiv_rn(s.X, s.Z) * fx + cx;
+  const float v = __fdiv_rn(s.Y, s.Z) * fy + cy;
+  s.valid = in_range && (u > 1.0f && v > 1.0f && u < wlim && v < hlim);  // optimizer.cpp:100 (NaN-safe form)
+  s.ix = s.valid ? (int)u : 1;
+  s.iy = s.valid ? (int)v : 1;
+  s.dx = u - (float)s.ix;
+  s.dy = v - (float)s.iy;
+  if (!s.valid) { s.X = 0.0f; s.Y = 0.0f; s.Z = 1.0f; s.dx = 0.0f; s.dy = 0.0f; }
+  return s;
+}
+
+// calcErrorAndBuffers' interpolation + filter + Huber (optimizer.cpp:106-133, optimizer.h:156-185)
+// fused with calculateWarpUpdate's Jacobian (optimizer.cpp:218-228) and LGS6::update.
+__device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch& q, float fx, float fy, float ed, bool filt,
+                                                 float huber, float* acc) {
+  // the reference's table entries at the four corners: (0.5(prev-next), 0.5(up-down), dt)
+  const float gx00 = 0.5f * (q.b0 - q.b2), gy00 = 0.5f * (q.a0 - q.c1), d00 = q.b1;
+  const float gx10 = 0.5f * (q.b1 - q.b3), gy10 = 0.5f * (q.a1 - q.c2), d10 = q.b2;
+  const float gx01 = 0.5f * (q.c0 - q.c2), gy01 = 0.5f * (q.b1 - q.d0), d01 = q.c1;
+  const float gx11 = 0.5f * (q.c1 - q.c3), gy11 = 0.5f * (q.b2 - q.d1), d11 = q.c2;
+  const float dxdy = s.dx * s.dy;
+  const float w11 = dxdy, w01 = s.dy - dxdy, w10 = s.dx - dxdy, w00 = ((1.0f - s.dx) - s.dy) + dxdy;
+  float r0 = ((w11 * gx11 + w01 * gx01) + w10 * gx10) + w00 * gx00;
+  float r1 = ((w11 * gy11 + w01 * gy01) + w10 * gy10) + w00 * gy00;
+  float res = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
+  const bool good = s.valid && !(res > ed && filt);  // optimizer.cpp:108
+  if (!good) { r0 = 0.0f; r1 = 0.0f; res = 0.0f; }
+  const float wr = (res <= huber) ? 1.0f : __fdiv_rn(huber, res);
+  const float gx = fx * r0, gy = fy * r1;
+  const float z = __fdiv_rn(1.0f, s.Z);
+  const float zs = z * z;  // reference: 1/(pz*pz), optimizer.cpp:213; differs by <= 1 ulp
+  float jv[6];
+  jv[0] = z * gx;
+  jv[1] = z * gy;
+  jv[2] = (-s.X * zs) * gx + (-s.Y * zs) * gy;
+  jv[3] = (-s.X * s.Y * zs) * gx + (-(1.0f + s.Y * s.Y * zs)) * gy;
+  jv[4] = (1.0f + s.X * s.X * zs) * gx + (s.X * s.Y * zs) * gy;
+  jv[5] = (-s.Y * z) * gx + (s.X * z) * gy;
+  float wv[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) wv[a] = wr * jv[a];
+  {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = a; c < 6; ++c) { acc[k] = fmaf(wv[a], jv[c], acc[k]); ++k; }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) acc[21 + a] = fmaf(wv[a], res, acc[21 + a]);
+  const float r2 = res * res;
+  acc[27] = fmaf(wr, r2, acc[27]);
+  acc[28] += r2;
+  acc[29] += good ? 1.0f : 0.0f;
+}
+
+#ifndef TRACK_MAXP
+#define TRACK_MAXP 8                  // points of a level kept in registers per thread
+#endif
+#define TRACK_LDS_DT_BYTES 76800        // DT planes up to 160x120 f32 are staged in LDS; 2 x (75 KB + 1.4 KB) fit one CU
+
+// Two points in flight: both projections, then all 24 DT gathers, then the math.
+template <typename PTR>
+__device__ __forceinline__ void eval_pair(const f4v p0, const f4v p1, bool has0, bool has1, PTR dtm, int w, const float* R,
+                                          const float* T, float fx, float fy, float cx, float cy, float wlim, float hlim,
+                                          float ed, bool filt, float huber, float* acc) {
+  const PtState s0 = project_point(p0, R, T, fx, fy, cx, cy, wlim, hlim, has0);
+  const PtState s1 = project_point(p1, R, T, fx, fy, cx, cy, wlim, hlim, has1);
+  const DtPatch q0 = load_patch(dtm, w, s0.ix, s0.iy);
+  const DtPatch q1 = load_patch(dtm, w, s1.ix, s1.iy);
+  accumulate_point(s0, q0, fx, fy, ed, filt, huber, acc);
+  accumulate_point(s1, q1, fx, fy, ed, filt, huber, acc);
+}
+
+template <typename PTR>
+__device__ __forceinline__ void eval_one(const f4v p0, PTR dtm, int w, const float* R, const float* T, float fx, float fy,
+                                         float cx, float cy, float wlim, float hlim, float ed, bool filt, float huber,
+                                         float* acc) {
+  const PtState s0 = project_point(p0, R, T, fx, fy, cx, cy, wlim, hlim, true);
+  const DtPatch q0 = load_patch(dtm, w, s0.ix, s0.iy);
+  accumulate_point(s0, q0, fx, fy, ed, filt, huber, acc);
+}
+
+// TrackerNew::evalCostFunction's per-point term, tracker.cpp:371-389
+template <typename PTR>
+__device__ __forceinline__ float cost_point(const f4v p, PTR dtm, int w, int h, const float* R, const float* T, float fx,
+                                            float fy, float cx, float cy, float ed, bool filt) {
+  const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
+  const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
+  const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
+  const float u = __fdiv_rn(fx * X, Z) + cx;
+  const float v = __fdiv_rn(fy * Y, Z) + cy;
+  float c = 0.0f;
+  if (u >= 0 && u < (float)w && v >= 0 && v < (float)h) {
+    const float r = dtm[(int)floorf(v) * w + (int)floorf(u)];
+    if (!(r > ed && filt)) c = r;
+  }
+  return c;
+}
+
+// One residual evaluation over this thread's share of the level: the first TRACK_MAXP points
+// come from registers (loaded once per level), any overflow streams from HBM/L2.
+template <typename PTR>
+__device__ __forceinline__ void eval_level(const f4v* preg, gf4p pts, int first, int stride, int N, PTR dtm, int w,
+                                           const float* R, const float* T, float fx, float fy, float cx, float cy,
+                                           float wlim, float hlim, float ed, bool filt, float huber, float* acc) {
+#pragma unroll
+  for (int k = 0; k < TRACK_MAXP; ++k) {
+    if (first + k * stride < N) eval_one(preg[k], dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
+    __builtin_amdgcn_sched_barrier(0);  // keep the unrolled points sequential: 4 waves/SIMD hide the latency, not ILP
+  }
+  for (int i = first + TRACK_MAXP * stride; i < N; i += stride)
+    eval_one(pts[i], dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
+}
+
+template <typename PTR>
+__device__ __forceinline__ float cost_level(const f4v* preg, gf4p pts, int first, int stride, int N, PTR dtm, int w, int h,
+                                            const float* R, const float* T, float fx, float fy, float cx, float cy, float ed,
+                                            bool filt) {
+  float cost = 0.0f;
+#pragma unroll
+  for (int k = 0; k < TRACK_MAXP; ++k)
+    if (first + k * stride < N) cost += cost_point(preg[k], dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
+  for (int i = first + TRACK_MAXP * stride; i < N; i += stride)
+    cost += cost_point(pts[i], dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
+  return cost;
+}
+
 // ---- the kernel ---------------------------------------------------------------
 __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restrict__ descs, TrackParams prm,
-                                                         revo_pair_result* __restrict__ out, EvalOut* __restrict__ eval_out) {
+                                                         revo_pair_result* __restrict__ out, EvalOut* __restrict__ eval_out,
+                                                         u64* __restrict__ mail, int n_pairs, int cluster) {
   __shared__ Ctrl s_ctrl;
   __shared__ W0State s;
   __shared__ float s_part[NWAVES][32];
-  const PairDesc& d = descs[blockIdx.x];
+  extern __shared__ __attribute__((aligned(16))) float s_dt[];  // TRACK_LDS_DT_BYTES: coarse-level DT plane
+  // XCD-affine mapping: all members of a pair share blockIdx % 8 (speed only, never correctness)
+  const int b = blockIdx.x;
+  const int pair = (b / (8 * cluster)) * 8 + (b % 8);
+  const int member = (b / 8) % cluster;
+  if (pair >= n_pairs) return;
+  const PairDesc& d = descs[pair];
+  u64* mail_pair = mail + (size_t)pair * 2 * cluster * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stride = cluster * TRACK_THREADS;
+  const int first = member * TRACK_THREADS + tid;
+  unsigned epoch = 0;
+  int cur_level = -1;
+  bool dt_in_lds = false;
+  f4v preg[TRACK_MAXP > 0 ? TRACK_MAXP : 1];
+#pragma unroll
+  for (int k = 0; k < TRACK_MAXP; ++k) preg[k] = f4v{0.f, 0.f, 1.f, 1.f};
 
   if (wave == 0) {  // ---- initial control word
     float R0[9], T0[3];
@@ -260,6 +477,9 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
       s.good = 0; s.bad = 0; s.sumw = 0.f; s.sumu = 0.f;
 #pragma unroll
       for (int i = 0; i < REVO_L; ++i) s.evals[i] = 0;
+#ifdef REVO_TRACK_PROFILE
+      for (int i = 0; i < 6; ++i) s.prof[i] = 0;
+#endif
 #pragma unroll
       for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rp[i];
 #pragma unroll
@@ -274,92 +494,59 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
     const int mode = s_ctrl.mode;
     if (mode == MODE_DONE) break;
     const int l = s_ctrl.level;
-    float R[9], T[3];
+    float R[9], T[3];  // wave-uniform: keep them in SGPRs
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = s_ctrl.R[i];
+    for (int i = 0; i < 9; ++i) R[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ctrl.R[i])));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) T[i] = s_ctrl.T[i];
+    for (int i = 0; i < 3; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ctrl.T[i])));
     const float fx = prm.cam[l].fx, fy = prm.cam[l].fy, cx = prm.cam[l].cx, cy = prm.cam[l].cy;
     const int w = prm.cam[l].w, h = prm.cam[l].h;
-    const float4* __restrict__ pts = d.pts[l];
+    gf4p pts = (gf4p)d.pts[l];
+    gf32p dtm = (gf32p)d.dt[l];
     const int N = d.npts[l];
+    ++epoch;
+#ifdef REVO_TRACK_PROFILE
+    const long long tp0 = clock64();
+#endif
 
+    if (l != cur_level) {
+      // Level entry (block-uniform): this thread's points go to registers for every evaluation
+      // of the level -- only the pose changes between them (optimizer.cpp:250-305) -- and a
+      // DT plane that fits is staged in LDS, so coarse-level evaluations never wait on HBM/L2.
+      cur_level = l;
+#pragma unroll
+      for (int k = 0; k < TRACK_MAXP; ++k) {
+        const int i = first + k * stride;
+        preg[k] = (i < N) ? pts[i] : f4v{0.f, 0.f, 1.f, 1.f};
+      }
+      dt_in_lds = (size_t)w * h * sizeof(float) <= TRACK_LDS_DT_BYTES;
+      if (dt_in_lds) {
+        const int n4 = (w * h) / 4;
+        gf4p src = (gf4p)d.dt[l];
+        f4v* dst = reinterpret_cast<f4v*>(s_dt);
+        for (int i = tid; i < n4; i += TRACK_THREADS) dst[i] = src[i];
+        __syncthreads();
+      }
+    }
+    const float ed = prm.edge_distance[l];
+    const bool filt = prm.use_edge_filter != 0;
     if (mode == MODE_COST) {
       // TrackerNew::evalCostFunction, tracker.cpp:357-393: nearest-pixel DT lookup
-      const float* __restrict__ dtm = d.dt_coarse;
-      const float ed = prm.edge_distance[l];
-      float cost = 0.0f;
-      for (int i = tid; i < N; i += TRACK_THREADS) {
-        const float4 p = pts[i];
-        const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
-        const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
-        const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
-        const float u = __fdiv_rn(fx * X, Z) + cx;
-        const float v = __fdiv_rn(fy * Y, Z) + cy;
-        if (u >= 0 && u < (float)w && v >= 0 && v < (float)h) {
-          const float r = dtm[(int)floorf(v) * w + (int)floorf(u)];
-          if (!(r > ed && prm.use_edge_filter)) cost += r;
-        }
-      }
+      float cost = dt_in_lds ? cost_level(preg, pts, first, stride, N, (const float*)s_dt, w, h, R, T, fx, fy, cx, cy, ed, filt)
+                             : cost_level(preg, pts, first, stride, N, dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) cost += __shfl_xor(cost, m);
-      if (lane == 0) s_part[wave][0] = cost;
+      if (lane < 32) s_part[wave][lane] = (lane == 0) ? cost : 0.0f;
     } else {
-      // calcErrorAndBuffers (optimizer.cpp:74-134) fused with calculateWarpUpdate
-      // (optimizer.cpp:197-231) and LGS6::update (LGSX.h:392-398)
-      const float4* __restrict__ tab = d.table[l];
-      const float ed = prm.edge_distance[l];
       const float huber = prm.huber_edge;
-      const bool filt = prm.use_edge_filter != 0;
       const float wlim = (float)(w - 2), hlim = (float)(h - 2);
       float acc[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-      for (int i = tid; i < N; i += TRACK_THREADS) {
-        const float4 p = pts[i];
-        const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
-        const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
-        const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
-        const float u = __fdiv_rn(X, Z) * fx + cx;
-        const float v = __fdiv_rn(Y, Z) * fy + cy;
-        if (!(u > 1.0f && v > 1.0f && u < wlim && v < hlim)) continue;  // optimizer.cpp:100
-        const int ix = (int)u, iy = (int)v;
-        const float dx = u - (float)ix, dy = v - (float)iy;
-        const float dxdy = dx * dy;
-        const float4* bp = tab + ix + iy * w;
-        const float4 t00 = bp[0], t10 = bp[1], t01 = bp[w], t11 = bp[w + 1];
-        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = ((1.0f - dx) - dy) + dxdy;
-        const float r0 = ((w11 * t11.x + w01 * t01.x) + w10 * t10.x) + w00 * t00.x;
-        const float r1 = ((w11 * t11.y + w01 * t01.y) + w10 * t10.y) + w00 * t00.y;
-        const float res = ((w11 * t11.z + w01 * t01.z) + w10 * t10.z) + w00 * t00.z;
-        if (res > ed && filt) continue;  // optimizer.cpp:108
-        const float wr = (res <= huber) ? 1.0f : __fdiv_rn(huber, res);  // optimizer.h:156-160
-        const float gx = fx * r0, gy = fy * r1;
-        const float z = __fdiv_rn(1.0f, Z), zs = __fdiv_rn(1.0f, Z * Z);
-        float jv[6];  // optimizer.cpp:218-228
-        jv[0] = z * gx;
-        jv[1] = z * gy;
-        jv[2] = (-X * zs) * gx + (-Y * zs) * gy;
-        jv[3] = (-X * Y * zs) * gx + (-(1.0f + Y * Y * zs)) * gy;
-        jv[4] = (1.0f + X * X * zs) * gx + (X * Y * zs) * gy;
-        jv[5] = (-Y * z) * gx + (X * z) * gy;
-        float wv[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) wv[a] = wr * jv[a];
-        {
-          int k = 0;
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = a; c < 6; ++c) { acc[k] = fmaf(wv[a], jv[c], acc[k]); ++k; }
-        }
-#pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] = fmaf(wv[a], res, acc[21 + a]);
-        const float r2 = res * res;
-        acc[27] = fmaf(wr, r2, acc[27]);
-        acc[28] += r2;
-        acc[29] += 1.0f;
-      }
+      if (dt_in_lds)
+        eval_level(preg, pts, first, stride, N, (const float*)s_dt, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
+      else
+        eval_level(preg, pts, first, stride, N, dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
       butterfly_step<16, 32>(acc, lane);
       butterfly_step<8, 16>(acc, lane);
       butterfly_step<4, 8>(acc, lane);
@@ -368,14 +555,29 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
       acc[0] += __shfl_xor(acc[0], 1);
       if ((lane & 1) == 0) s_part[wave][lane >> 1] = acc[0];
     }
+#ifdef REVO_TRACK_PROFILE
+    const long long tp1 = clock64();
+#endif
     __syncthreads();
+#ifdef REVO_TRACK_PROFILE
+    const long long tp2 = clock64();
+    long long tp3 = tp2, tp4 = tp2, tp5 = tp2;
+#endif
 
-    if (wave == 0) {  // ---- wave 0: totals, LM decision, next pose (all lanes uniform)
+    if (wave == 0) {  // ---- wave 0: totals, cluster exchange, LM decision, next pose (all lanes uniform)
       double tot = 0.0;
       if (lane < 32) {
 #pragma unroll
         for (int wv = 0; wv < NWAVES; ++wv) tot += (double)s_part[wv][lane];
       }
+#ifdef REVO_TRACK_PROFILE
+      tp3 = clock64();
+#endif
+      bool exchange_ok = true;
+      if (cluster > 1) exchange_ok = cluster_allgather(mail_pair, cluster, member, epoch, (float)tot, lane, &tot);
+#ifdef REVO_TRACK_PROFILE
+      tp4 = clock64();
+#endif
       int phase = s.phase;
       int next_mode = MODE_EVAL, next_level = l;
       bool new_candidate = false;  // solve + exp on the accepted state
@@ -390,13 +592,15 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
       int total_evals = s.total_evals + 1;
       int flags = s.flags;
 
-      if (mode == MODE_COST) {
+      if (!exchange_ok) {  // a cluster member never showed up: give up loudly instead of hanging
+        flags |= 8;
+        next_mode = MODE_DONE;
+      } else if (mode == MODE_COST) {
         const float cost = (float)__shfl(tot, 0);
         if (phase == PH_COST_EYE) {
           if (lane == 0) s.costEye = cost;
           phase = PH_COST_INIT;
           next_mode = MODE_COST;
-          // next: cost at the given init pose (still in s.q/s.t as R0,T0 from the descriptor)
           if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) s_ctrl.R[i] = d.R[i];
@@ -443,8 +647,8 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
           const double an = tot / n_d;
           if (lane < 27) s.Aacc[lane] = an;
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          if (lane == 0) {
-            EvalOut& eo = eval_out[blockIdx.x];
+          if (lane == 0 && member == 0) {
+            EvalOut& eo = eval_out[pair];
             int k = 0;
             for (int r = 0; r < 6; ++r)
               for (int c = r; c < 6; ++c) { const float v = (float)s.Aacc[k++]; eo.A[r * 6 + c] = v; eo.A[c * 6 + r] = v; }
@@ -538,11 +742,20 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
         s_ctrl.level = next_level;
         s_ctrl.mode = next_mode;
       }
+#ifdef REVO_TRACK_PROFILE
+      tp5 = clock64();
+#endif
     }
     __syncthreads();
+#ifdef REVO_TRACK_PROFILE
+    if (tid == 0) {
+      const long long tp6 = clock64();
+      s.prof[0] += tp1 - tp0; s.prof[1] += tp2 - tp1; s.prof[2] += tp3 - tp2; s.prof[3] += tp4 - tp3; s.prof[4] += tp5 - tp4; s.prof[5] += tp6 - tp5;
+    }
+#endif
   }
 
-  if (tid == 0 && !prm.eval_only) {
+  if (tid == 0 && member == 0 && !prm.eval_only) {
     revo_pair_result r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.R[i] = s_ctrl.R[i];
@@ -555,15 +768,28 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
     r.status = ((double)s.good / (double)s.bad < 4.0) ? REVO_TRACKER_STATE_NEW_KF : REVO_TRACKER_STATE_OK;
 #pragma unroll
     for (int i = 0; i < REVO_L; ++i) r.evals[i] = s.evals[i];
+#ifdef REVO_TRACK_PROFILE
+    for (int i = 0; i < 6; ++i) r.evals[i] = (int)(s.prof[i] / 16);  // profile build: phase cycles / 16
+#endif
     r.flags = s.flags;
     r.n_pts0 = d.npts[0];
-    out[blockIdx.x] = r;
+    out[pair] = r;
   }
 }
 
 }  // namespace
 
+int track_blocks_per_cu() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_track, TRACK_THREADS, TRACK_LDS_DT_BYTES) != hipSuccess) nb = 1;
+  return nb < 1 ? 1 : nb;
+}
+
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval, int n_pairs,
-                  hipStream_t s) {
-  hipLaunchKernelGGL(k_track, dim3(n_pairs), dim3(TRACK_THREADS), 0, s, d_descs, prm, d_out, d_eval);
+                  unsigned long long* d_mail, int cluster, hipStream_t s) {
+  // granules carry epochs that restart at 1 every launch: zero the mailbox first (stream ordered)
+  if (cluster > 1) hipMemsetAsync(d_mail, 0, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32, s);
+  const int groups = (n_pairs + 7) / 8;
+  hipLaunchKernelGGL(k_track, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), TRACK_LDS_DT_BYTES, s, d_descs, prm, d_out,
+                     d_eval, (u64*)d_mail, n_pairs, cluster);
 }
