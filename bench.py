@@ -52,6 +52,7 @@ def main():
                     "else render and save (profilers deadlock on the forked render pool)")
     ap.add_argument("--render-procs", type=int, default=0, help="0 = auto")
     ap.add_argument("--no-overlap", action="store_true", help="single batch, single stream (no build/track overlap)")
+    ap.add_argument("--single-stream-frames", type=int, default=60, help="0 = skip the sequential-VO side measurement")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +220,35 @@ def main():
         "evals_raw_mean": [float(x) for x in np.array([r["evals"] for r in res], np.float64).mean(0)],
         "input_render_s": t_render,
     }
+
+    # ---- side measurement: ONE sequential stream through the host-buffer API (BASELINE configs[1]
+    # stand-in: no TUM data here).  Frame N depends on frame N-1, so this is latency-bound and
+    # PCIe-inclusive; it is reported next to, never as, `value`.
+    if rank == 0 and world == 1 and a.single_stream_frames > 0:
+        from revo_amd import vo
+        n = a.single_stream_frames
+        seq = [(rendered[i % a.pairs][2 * (i % 2)], rendered[i % a.pairs][2 * (i % 2) + 1]) for i in range(2)]
+        drv = vo.REVO(s, cameraPyr=cam)
+        # ref/curr of pair 0 alternate (a tiny known motion): enough to time the sequential path
+        stream_frames = [(seq[i % 2][0], seq[i % 2][1], float(i) / 30.0) for i in range(n)]
+        drv.run(stream_frames[:4])  # warm-up (pools, first-touch)
+        drv = vo.REVO(s, cameraPyr=cam)
+        t0 = time.perf_counter()
+        drv.run(stream_frames)
+        dt_seq = time.perf_counter() - t0
+        cpu_seq = None
+        if a.cpu_baseline != "off":  # the same stream through the oracle's REVO::start restatement, 1 core
+            from oracle import ro
+            ovo = ro.VO(s)
+            t0 = time.perf_counter()
+            for fr in stream_frames[: min(n, 40)]:
+                ovo.push(*fr)
+            cpu_seq = min(n, 40) / (time.perf_counter() - t0)
+        out["single_stream"] = {"frames_per_s": n / dt_seq, "frames": n, "keyframes": drv.nKeyFrames,
+                                "cpu_oracle_frames_per_s_1core": cpu_seq,
+                                "speedup_vs_cpu_oracle": (n / dt_seq / cpu_seq) if cpu_seq else None,
+                                "note": "sequential REVO::start sequencing (revo_vo_*) via the host-buffer C ABI: H2D copy, "
+                                        "pyramid, trackFrames, quality vote per frame, one frame of look-ahead"}
 
     # ---- CPU baseline: the oracle (plain-C port, 1 core) on a bounded sample of the same workload
     if rank == 0 and world == 1 and a.cpu_baseline != "off":

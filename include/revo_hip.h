@@ -130,6 +130,9 @@ void revo_ctx_destroy(revo_ctx* ctx);
 int revo_ctx_set_tracker(revo_ctx* ctx, const revo_opt_settings* opt,
                          const revo_tracker_settings* trk);
 
+/* TrackerNew::histogramLevel (tracker.h:67, tracker.cpp:229). */
+int revo_ctx_histogram_level(const revo_ctx* ctx);
+
 /* Camera(fx,fy,cx,cy,w,h,scale) for level lvl, camerapyr.h:98-103,139-144:
  * out6 = {fx,fy,cx,cy,width,height}. */
 int revo_ctx_camera(const revo_ctx* ctx, int lvl, float out6[6]);
@@ -259,6 +262,27 @@ int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out);
 int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT,
                             revo_pair_result* d_results, void* stream, int reps,
                             float* ms_mean);
+
+/* ---- REVO::start sequencing (system/system.cpp:84-305) ----------------------- */
+
+/* The reference runs two threads: IOWrapperRGBD::generateImgPyramid builds pyramids into a
+ * queue (iowrapperRGBD.cpp:257-300), REVO::start consumes the oldest one per loop body
+ * (system.cpp:128-284).  revo_vo_submit is the producer side (asynchronous: the build of
+ * frame N+1 overlaps the tracking of frame N on the device), revo_vo_track_next the consumer:
+ * first frame -> keyframe; later frames: trackFrames against the keyframe,
+ * assessTrackingQuality, optional promotion of the PREVIOUS frame to keyframe + re-track
+ * (system.cpp:203-241), constant-velocity initialisation of the next frame (267-271). */
+typedef struct revo_vo revo_vo;
+int revo_vo_create(revo_ctx* ctx, revo_vo** out);
+void revo_vo_destroy(revo_vo* vo);
+int revo_vo_submit(revo_vo* vo, const uint8_t* bgr, size_t bgr_stride,
+                   const float* depth_m, size_t depth_stride, double timestamp);
+/* pose_colmajor: 4x4 curr->world as REVO::writePose would emit it (system.cpp:275);
+ * *new_keyframe: 1 if this frame created a keyframe.  REVO_ERR_INVALID_ARG if the queue is empty. */
+int revo_vo_track_next(revo_vo* vo, float pose_colmajor[16], int* new_keyframe,
+                       double* timestamp);
+int revo_vo_queued(const revo_vo* vo);
+int revo_vo_num_keyframes(const revo_vo* vo);
 
 #ifdef __cplusplus
 }

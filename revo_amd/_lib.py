@@ -91,6 +91,14 @@ def lib():
     L.revo_batch_sync.argtypes = [vp, vp]
     L.revo_batch_frame.argtypes = [vp, C.c_int, vpp]
     L.revo_batch_time_tracker.argtypes = [vp, f32p, vp, vp, C.c_int, f32p]
+    L.revo_ctx_histogram_level.argtypes = [vp]
+    L.revo_vo_create.argtypes = [vp, vpp]
+    L.revo_vo_destroy.argtypes = [vp]
+    L.revo_vo_destroy.restype = None
+    L.revo_vo_submit.argtypes = [vp, u8p, C.c_size_t, f32p, C.c_size_t, C.c_double]
+    L.revo_vo_track_next.argtypes = [vp, f32p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.revo_vo_queued.argtypes = [vp]
+    L.revo_vo_num_keyframes.argtypes = [vp]
     _lib = L
     return L
 

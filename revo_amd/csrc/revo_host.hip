@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -66,6 +67,12 @@ struct FrameSet {
   FramePlanes p{};
   uint8_t* d_bgr = nullptr;   // input staging (single-frame API)
   float* d_depth = nullptr;   // input staging; aliased as u16 for the u16 entry point
+  // asynchronous creation (single-frame API): pinned host staging, "built" and "released" events
+  uint8_t* h_bgr = nullptr;
+  float* h_depth = nullptr;
+  hipEvent_t ev_ready = nullptr;  // recorded on the build stream after the last build kernel
+  hipEvent_t ev_free = nullptr;   // recorded on the tracker stream when the set goes back to the pool
+  bool has_ready = false, has_free = false;
 };
 
 struct Past {  // one entry of mPastPcl / mPastWorldPoses / mPastTimeStamps (tracker.h:92-95)
@@ -73,13 +80,18 @@ struct Past {  // one entry of mPastPcl / mPastWorldPoses / mPastTimeStamps (tra
 };
 
 struct revo_ctx {
+  // handles (pyramids, batches, VO drivers) keep their context alive: revo_ctx_destroy only drops
+  // the owner's reference, the last handle to go frees the device state
+  std::atomic<int> refs{1};
   int device;
   revo_pyr_settings ps; revo_opt_settings os; revo_tracker_settings ts;
   PyrGeom geom;
   TrackParams tp;
-  hipStream_t stream;
+  hipStream_t stream;        // tracker / consumer stream
+  hipStream_t build_stream;  // pyramid builds of the single-frame API (overlap with tracking, like the IO thread)
   std::mutex mu;
   std::vector<FrameSet*> pool;  // free single-frame FrameSets
+  std::vector<Past> past_pool;  // recycled past-cloud buffers (no hipMalloc per frame)
   // single-pair tracker scratch
   PairDesc* h_desc; PairDesc* d_desc;
   revo_pair_result* h_res; revo_pair_result* d_res;
@@ -240,14 +252,25 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       if (e != hipSuccess) { delete fs; return fail(REVO_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     }
   }
+  if (with_staging) {
+    HIPCHECK(hipHostMalloc((void**)&fs->h_bgr, (size_t)g.lv[0].npix * 3 * B));
+    HIPCHECK(hipHostMalloc((void**)&fs->h_depth, (size_t)g.lv[0].npix * 4 * B));
+    HIPCHECK(hipEventCreateWithFlags(&fs->ev_ready, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&fs->ev_free, hipEventDisableTiming));
+  }
   // counts start at zero so an accessor on a not-yet-built pyramid is well defined
   hipMemsetAsync(fs->p.npts, 0, sizeof(int) * REVO_L * B, c->stream);
+  HIPCHECK(hipStreamSynchronize(c->stream));
   *out = fs;
   return REVO_OK;
 }
 static void frameset_destroy(FrameSet* fs) {
   if (!fs) return;
   if (fs->blob) hipFree(fs->blob);
+  if (fs->h_bgr) hipHostFree(fs->h_bgr);
+  if (fs->h_depth) hipHostFree(fs->h_depth);
+  if (fs->ev_ready) hipEventDestroy(fs->ev_ready);
+  if (fs->ev_free) hipEventDestroy(fs->ev_free);
   delete fs;
 }
 
@@ -281,6 +304,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   if (build_geom(c->ps, &c->geom, &why)) { delete c; return fail(REVO_ERR_INVALID_ARG, why); }
   build_track_params(c, &c->tp);
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHECK(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
   HIPCHECK(hipMalloc((void**)&c->d_desc, sizeof(PairDesc)));
   HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result)));
@@ -307,11 +331,13 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   return REVO_OK;
 }
 
-extern "C" void revo_ctx_destroy(revo_ctx* c) {
-  if (!c) return;
+static void ctx_free(revo_ctx* c) {
   hipSetDevice(c->device);
+  hipStreamSynchronize(c->build_stream);
   hipStreamSynchronize(c->stream);
   for (auto& p : c->past) { hipFree(p.d_pts); hipFree(p.d_n); }
+  for (auto& p : c->past_pool) { hipFree(p.d_pts); hipFree(p.d_n); }
+  hipStreamDestroy(c->build_stream);
   for (FrameSet* fs : c->pool) frameset_destroy(fs);
   hipHostFree(c->h_desc); hipFree(c->d_desc); hipHostFree(c->h_res); hipFree(c->d_res);
   hipHostFree(c->h_eval); hipFree(c->d_eval); hipFree(c->d_mail);
@@ -321,6 +347,12 @@ extern "C" void revo_ctx_destroy(revo_ctx* c) {
   hipStreamDestroy(c->stream);
   delete c;
 }
+static void ctx_ref(revo_ctx* c) { c->refs.fetch_add(1); }
+static void ctx_unref(revo_ctx* c) { if (c->refs.fetch_sub(1) == 1) ctx_free(c); }
+extern "C" void revo_ctx_destroy(revo_ctx* c) { if (c) ctx_unref(c); }
+// used by revo_vo.hip
+extern "C" void revo_ctx_retain_(revo_ctx* c) { if (c) ctx_ref(c); }
+extern "C" void revo_ctx_release_(revo_ctx* c) { if (c) ctx_unref(c); }
 
 extern "C" int revo_ctx_set_tracker(revo_ctx* c, const revo_opt_settings* opt, const revo_tracker_settings* trk) {
   if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
@@ -331,6 +363,8 @@ extern "C" int revo_ctx_set_tracker(revo_ctx* c, const revo_opt_settings* opt, c
   return REVO_OK;
 }
 
+extern "C" int revo_ctx_histogram_level(const revo_ctx* c) { return c ? c->ts.histogram_level : -1; }
+
 extern "C" int revo_ctx_camera(const revo_ctx* c, int lvl, float out6[6]) {
   if (!c || !out6) return fail(REVO_ERR_INVALID_ARG, "null argument");
   if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
@@ -340,6 +374,12 @@ extern "C" int revo_ctx_camera(const revo_ctx* c, int lvl, float out6[6]) {
 }
 
 // ----------------------------------------------------------------- pyramids --
+// Order the consumer stream after the (asynchronous) build of a single-frame pyramid.
+static int wait_ready(revo_ctx* c, const revo_pyr* p) {
+  if (p->owns_fs && p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
+  return REVO_OK;
+}
+
 static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_stride, const void* depth,
                                  size_t depth_stride, bool is_u16, double scale, double ts, revo_pyr** out) {
   if (!c || !bgr || !depth || !out) return fail(REVO_ERR_INVALID_ARG, "null argument");
@@ -356,17 +396,25 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
     int rc = frameset_create(c, 1, true, &fs);
     if (rc) return rc;
   }
-  // The reference clones its inputs (imgpyramidrgbd.cpp:51,54): the copies below are
-  // complete (w.r.t. the caller's buffers) when these calls return.
-  HIPCHECK(hipMemcpy2DAsync(fs->d_bgr, (size_t)w * 3, bgr, bgr_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
-  const size_t drow = (size_t)w * (is_u16 ? 2 : 4);
-  HIPCHECK(hipMemcpy2DAsync(fs->d_depth, drow, depth, depth_stride, drow, h, hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream));  // pageable sources: make the clone guarantee explicit
+  // The reference clones its inputs (imgpyramidrgbd.cpp:51,54): the host copy into the pinned
+  // staging area below is that clone -- the caller may reuse its buffers when this returns.
+  // Everything after it is asynchronous on the build stream, so building frame N+1 overlaps
+  // tracking frame N exactly like the reference's IO thread (iowrapperRGBD.cpp:279, system.cpp:96).
+  if (fs->has_ready) HIPCHECK(hipEventSynchronize(fs->ev_ready));  // previous upload out of this staging is done
+  const size_t brow = (size_t)w * 3, drow = (size_t)w * (is_u16 ? 2 : 4);
+  for (int y = 0; y < h; ++y) memcpy(fs->h_bgr + (size_t)y * brow, bgr + (size_t)y * bgr_stride, brow);
+  for (int y = 0; y < h; ++y) memcpy((char*)fs->h_depth + (size_t)y * drow, (const char*)depth + (size_t)y * depth_stride, drow);
+  hipStream_t bs = c->build_stream;
+  if (fs->has_free) HIPCHECK(hipStreamWaitEvent(bs, fs->ev_free, 0));  // last consumer of the recycled set is done
+  HIPCHECK(hipMemcpyAsync(fs->d_bgr, fs->h_bgr, brow * h, hipMemcpyHostToDevice, bs));
+  HIPCHECK(hipMemcpyAsync(fs->d_depth, fs->h_depth, drow * h, hipMemcpyHostToDevice, bs));
   const float alpha = is_u16 ? (float)(1.0f / scale) : 0.0f;  // iowrapperRGBD.cpp:327
-  enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha,
-                c->stream);
+  enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha, bs);
   HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(fs->ev_ready, bs));
+  fs->has_ready = true;
   revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts, false};
+  ctx_ref(c);
   *out = p;
   return REVO_OK;
 }
@@ -384,16 +432,23 @@ extern "C" int revo_pyramid_create_u16(revo_ctx* ctx, const uint8_t* bgr, size_t
 extern "C" void revo_pyramid_destroy(revo_pyr* p) {
   if (!p) return;
   if (p->owns_fs) {
-    // stream-ordered reuse: later work on the same stream runs after everything that reads this set
+    // reuse is ordered by events: the next build into this set waits for everything the
+    // consumer stream has enqueued against it so far
+    hipSetDevice(p->ctx->device);
     std::lock_guard<std::mutex> lk(p->ctx->mu);
+    hipEventRecord(p->fs->ev_free, p->ctx->stream);
+    p->fs->has_free = true;
     p->ctx->pool.push_back(p->fs);
   }
+  revo_ctx* c = p->owns_fs ? p->ctx : nullptr;
   delete p;
+  if (c) ctx_unref(c);
 }
 
 extern "C" int revo_pyramid_make_keyframe(revo_pyr* p) {
   if (!p) return fail(REVO_ERR_INVALID_ARG, "null pyramid");
   HIPCHECK(hipSetDevice(p->ctx->device));
+  { int rc = wait_ready(p->ctx, p); if (rc) return rc; }
   launch_keyframe(p->ctx->geom, p->fs->p, p->frame, 1, 1, p->ctx->stream);
   HIPCHECK(hipGetLastError());
   p->is_kf = true;
@@ -411,6 +466,7 @@ extern "C" int revo_pyramid_read(revo_pyr* p, revo_plane what, int lvl, void* ds
   const LevelGeom& v = c->geom.lv[lvl];
   const FramePlanes& P = p->fs->p;
   const size_t f = (size_t)p->frame;
+  { int rc = wait_ready(c, p); if (rc) return rc; }
   HIPCHECK(hipStreamSynchronize(c->stream));
   const void* src = nullptr;
   size_t n = v.npix, esz = 1;
@@ -474,6 +530,7 @@ static int check_pair(const revo_ctx* c, const revo_pyr* ref, const revo_pyr* cu
 static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
                       const TrackParams& tp) {
   fill_desc(c->h_desc, ref, curr, R, T);
+  { int rc = wait_ready(c, ref); if (rc) return rc; rc = wait_ready(c, curr); if (rc) return rc; }
   HIPCHECK(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PairDesc), hipMemcpyHostToDevice, c->stream));
   launch_track(c->d_desc, tp, c->d_res, c->d_eval, 1, c->d_mail, pick_cluster(c, 1), c->stream);
   HIPCHECK(hipGetLastError());
@@ -588,6 +645,7 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
   const int hl = c->ts.histogram_level;
   if (hl < 0 || hl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "histogram_level outside the pyramid");
   HIPCHECK(hipSetDevice(c->device));
+  { int rc = wait_ready(c, curr); if (rc) return rc; }
   float inv[16];
   mat4_inverse(T_w_curr, inv);
   int nframes = 0;
@@ -627,17 +685,23 @@ extern "C" int revo_tracker_add_old_pcl(revo_ctx* c, const revo_pyr* src, int lv
   if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
   HIPCHECK(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
-  // the reference copies the Eigen matrix (tracker.cpp:219); the copy stays in HBM
+  // the reference copies the Eigen matrix (tracker.cpp:219); the copy stays in HBM, in a
+  // recycled buffer sized for the level (no hipMalloc per frame)
+  { int rc = wait_ready(c, src); if (rc) return rc; }
   Past p{};
   const size_t f = (size_t)src->frame;
-  HIPCHECK(hipMemcpyAsync(c->h_hist8, src->fs->p.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream));
-  p.n = c->h_hist8[0];
-  HIPCHECK(hipMalloc((void**)&p.d_pts, sizeof(float4) * (size_t)std::max(1, p.n)));
-  HIPCHECK(hipMalloc((void**)&p.d_n, sizeof(int)));
-  HIPCHECK(hipMemcpyAsync(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, sizeof(float4) * (size_t)p.n,
+  if (!c->past_pool.empty()) { p = c->past_pool.back(); c->past_pool.pop_back(); }
+  else {
+    size_t maxpix = 0;
+    for (int l = 0; l < c->geom.n_levels; ++l) maxpix = std::max(maxpix, (size_t)c->geom.lv[l].npix);
+    HIPCHECK(hipMalloc((void**)&p.d_pts, sizeof(float4) * maxpix));
+    HIPCHECK(hipMalloc((void**)&p.d_n, sizeof(int)));
+  }
+  // the count stays on the device; the whole capacity of the level is copied (<= 300 KB at level 2)
+  HIPCHECK(hipMemcpyAsync(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, sizeof(float4) * (size_t)c->geom.lv[lvl].npix,
                           hipMemcpyDeviceToDevice, c->stream));
   HIPCHECK(hipMemcpyAsync(p.d_n, src->fs->p.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  p.n = -1;
   memcpy(p.T_w, T_w, sizeof(float) * 16);
   p.ts = ts;
   c->past.push_back(p);
@@ -648,9 +712,8 @@ extern "C" int revo_tracker_clear_past(revo_ctx* c) {  // tracker.cpp:248-257
   if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
   HIPCHECK(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
-  HIPCHECK(hipStreamSynchronize(c->stream));
-  while ((int)c->past.size() > c->ts.n_frames_hist_voting) {
-    hipFree(c->past.front().d_pts); hipFree(c->past.front().d_n);
+  while ((int)c->past.size() > c->ts.n_frames_hist_voting) {  // stream-ordered reuse of the buffers
+    c->past_pool.push_back(c->past.front());
     c->past.pop_front();
   }
   return REVO_OK;
@@ -663,8 +726,9 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipSetDevice(c->device));
   revo_batch* b = new revo_batch();
   b->ctx = c; b->n_pairs = n_pairs;
+  ctx_ref(c);
   int rc = frameset_create(c, 2 * n_pairs, false, &b->fs);
-  if (rc) { delete b; return rc; }
+  if (rc) { delete b; ctx_unref(c); return rc; }
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
   HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
@@ -686,7 +750,9 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   hipEventDestroy(b->ev0); hipEventDestroy(b->ev1); hipEventDestroy(b->ev_upload);
   hipStreamDestroy(b->stream);
   frameset_destroy(b->fs);
+  revo_ctx* c = b->ctx;
   delete b;
+  ctx_unref(c);
 }
 
 extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream) {

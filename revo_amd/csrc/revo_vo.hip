@@ -1,0 +1,164 @@
+// revo_vo.hip -- REVO::start sequencing (system/system.cpp:84-305) on top of the C ABI.
+// Host-only code: the device work is what revo_pyramid_* / revo_tracker_* enqueue.
+#include <cstring>
+#include <deque>
+
+#include "../../include/revo_hip.h"
+
+extern "C" void revo_ctx_retain_(revo_ctx*);
+extern "C" void revo_ctx_release_(revo_ctx*);
+
+namespace {
+struct M4 {  // column-major 4x4, Eigen::Matrix4f storage
+  float m[16];
+  static M4 identity() { M4 o; memset(o.m, 0, sizeof(o.m)); o.m[0] = o.m[5] = o.m[10] = o.m[15] = 1.f; return o; }
+};
+M4 mul(const M4& A, const M4& B) {
+  M4 o;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      o.m[c * 4 + r] = A.m[r] * B.m[c * 4] + A.m[4 + r] * B.m[c * 4 + 1] + A.m[8 + r] * B.m[c * 4 + 2] + A.m[12 + r] * B.m[c * 4 + 3];
+  return o;
+}
+M4 inverse(const M4& A) {  // Eigen Matrix4f::inverse(): general cofactor inverse, float
+  const float* m = A.m;
+  float o[16];
+  o[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  o[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  o[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  o[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  o[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  o[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  o[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  o[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  o[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  o[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  o[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  o[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  o[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  o[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  o[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  o[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const float det = m[0] * o[0] + m[1] * o[4] + m[2] * o[8] + m[3] * o[12];
+  const float idet = 1.0f / det;
+  M4 r;
+  for (int i = 0; i < 16; ++i) r.m[i] = o[i] * idet;
+  return r;
+}
+M4 from_RT(const float* R, const float* T) {  // transformFromRT
+  M4 o = M4::identity();
+  for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) o.m[c * 4 + r] = R[c * 3 + r];
+  o.m[12] = T[0]; o.m[13] = T[1]; o.m[14] = T[2];
+  return o;
+}
+void to_RT(const M4& M, float* R, float* T) {
+  for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) R[c * 3 + r] = M.m[c * 4 + r];
+  T[0] = M.m[12]; T[1] = M.m[13]; T[2] = M.m[14];
+}
+struct Pose { M4 T_kf_curr, T_w_kf; M4 world() const { return mul(T_w_kf, T_kf_curr); } };  // REVO::Pose, system.h:89-152
+struct Frame { revo_pyr* pyr; double ts; M4 T_w_f; };
+}  // namespace
+
+struct revo_vo {
+  revo_ctx* ctx;
+  std::deque<Frame> queue;  // mPyrQueue, iowrapperRGBD.h:166-167
+  Frame kf{nullptr, 0, M4::identity()}, prev{nullptr, 0, M4::identity()};
+  Pose last, before_last;
+  M4 T_NM1_N = M4::identity();
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0};
+  int no_frames = 0, n_keyframes = 0;
+  bool just_added_kf = false;
+  int hist_level = 2;
+};
+
+extern "C" int revo_vo_create(revo_ctx* ctx, revo_vo** out) {
+  if (!ctx || !out) return REVO_ERR_INVALID_ARG;
+  revo_vo* v = new revo_vo();
+  v->ctx = ctx;
+  revo_ctx_retain_(ctx);
+  v->hist_level = revo_ctx_histogram_level(ctx);
+  *out = v;
+  return REVO_OK;
+}
+extern "C" void revo_vo_destroy(revo_vo* v) {
+  if (!v) return;
+  for (auto& f : v->queue) revo_pyramid_destroy(f.pyr);
+  if (v->kf.pyr && v->kf.pyr != v->prev.pyr) revo_pyramid_destroy(v->kf.pyr);
+  if (v->prev.pyr) revo_pyramid_destroy(v->prev.pyr);
+  revo_ctx_release_(v->ctx);
+  delete v;
+}
+extern "C" int revo_vo_queued(const revo_vo* v) { return v ? (int)v->queue.size() : 0; }
+extern "C" int revo_vo_num_keyframes(const revo_vo* v) { return v ? v->n_keyframes : 0; }
+
+// IOWrapperRGBD::generateImgPyramidFromFiles: new ImgPyramidRGBD(...) -> queue (iowrapperRGBD.cpp:279-288)
+extern "C" int revo_vo_submit(revo_vo* v, const uint8_t* bgr, size_t bgr_stride, const float* depth, size_t depth_stride,
+                              double ts) {
+  if (!v) return REVO_ERR_INVALID_ARG;
+  Frame f{nullptr, ts, M4::identity()};
+  const int rc = revo_pyramid_create(v->ctx, bgr, bgr_stride, depth, depth_stride, ts, &f.pyr);
+  if (rc) return rc;
+  v->queue.push_back(f);
+  return REVO_OK;
+}
+
+// one body of the while loop of REVO::start (system.cpp:128-284)
+extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_out, double* ts_out) {
+  if (!v || v->queue.empty()) return REVO_ERR_INVALID_ARG;
+  Frame curr = v->queue.front();
+  v->queue.pop_front();
+  int rc, new_kf = 0, status = 0;
+  const M4 I = M4::identity();
+  if (ts_out) *ts_out = curr.ts;
+  if (v->no_frames == 0) {  // system.cpp:151-175
+    v->kf = v->prev = curr;
+    if ((rc = revo_pyramid_make_keyframe(v->kf.pyr))) return rc;
+    v->kf.T_w_f = I;
+    v->prev.T_w_f = I;
+    v->last = Pose{I, I};
+    ++v->n_keyframes;
+    ++v->no_frames;
+    v->just_added_kf = true;
+    if ((rc = revo_tracker_add_old_pcl(v->ctx, v->kf.pyr, v->hist_level, I.m, curr.ts))) return rc;
+    if (pose_out) memcpy(pose_out, I.m, sizeof(I.m));
+    if (new_kf_out) *new_kf_out = 1;
+    return REVO_OK;
+  }
+  ++v->no_frames;
+  float err = 0.f;
+  if ((rc = revo_tracker_track_frames(v->ctx, v->kf.pyr, curr.pyr, v->R, v->T, &err, &status, nullptr, nullptr))) return rc;
+  M4 T_KF_N = from_RT(v->R, v->T);
+  M4 currPoseInWorld = mul(v->kf.T_w_f, T_KF_N);
+  if ((rc = revo_tracker_assess_quality(v->ctx, currPoseInWorld.m, curr.pyr, &status, nullptr, nullptr))) return rc;
+  if (status == REVO_TRACKER_STATE_NEW_KF && !v->just_added_kf) {  // system.cpp:203-241
+    revo_pyr* old_kf = v->kf.pyr;
+    v->kf = v->prev;
+    v->kf.T_w_f = v->last.world();  // kfPyr->setTwf(mPoseGraph.back().getCurrToWorld())
+    if ((rc = revo_pyramid_make_keyframe(v->kf.pyr))) return rc;
+    v->last = Pose{I, v->kf.T_w_f};  // mPoseGraph.back().setKfFrame(kfPyr)
+    ++v->n_keyframes;
+    if ((rc = revo_tracker_clear_past(v->ctx))) return rc;
+    to_RT(v->T_NM1_N, v->R, v->T);
+    if ((rc = revo_tracker_track_frames(v->ctx, v->kf.pyr, curr.pyr, v->R, v->T, &err, &status, nullptr, nullptr))) return rc;
+    T_KF_N = from_RT(v->R, v->T);
+    currPoseInWorld = mul(v->kf.T_w_f, T_KF_N);
+    if ((rc = revo_tracker_assess_quality(v->ctx, currPoseInWorld.m, curr.pyr, &status, nullptr, nullptr))) return rc;
+    v->just_added_kf = true;
+    new_kf = 1;
+    if (old_kf != v->kf.pyr) revo_pyramid_destroy(old_kf);
+  } else {
+    v->just_added_kf = false;
+  }
+  v->before_last = v->last;
+  v->last = Pose{T_KF_N, v->kf.T_w_f};  // mPoseGraph.push_back(Pose(T_KF_N, ts, kfPyr))
+  if ((rc = revo_tracker_add_old_pcl(v->ctx, curr.pyr, v->hist_level, currPoseInWorld.m, curr.ts))) return rc;
+  // T_NM1_N = graph[size-2].T_N_W() * graph.back().T_W_N(); T_init = back().T_kf_N() * T_NM1_N (system.cpp:267-271)
+  const M4 w1 = v->last.world();
+  v->T_NM1_N = mul(inverse(v->before_last.world()), w1);
+  to_RT(mul(v->last.T_kf_curr, v->T_NM1_N), v->R, v->T);
+  if (pose_out) memcpy(pose_out, w1.m, sizeof(w1.m));
+  if (new_kf_out) *new_kf_out = new_kf;
+  if (v->prev.pyr != v->kf.pyr) revo_pyramid_destroy(v->prev.pyr);  // prevPyr = currPyr
+  v->prev = curr;
+  return REVO_OK;
+}

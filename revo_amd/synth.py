@@ -169,8 +169,9 @@ def make_pair(seed, settings, max_t=0.03, max_rot_deg=1.5, hole_frac=0.03):
     return dict(ref=ref, curr=curr, T_ref_curr=T_ref_curr, T_w_ref=T_w_ref, T_w_curr=T_w_curr)
 
 
-def make_sequence(seed, settings, n_frames, max_t=0.012, max_rot_deg=0.6, hole_frac=0.03):
-    """Smooth random-walk trajectory (TUM-like stand-in): list of (bgr, depth, ts, T_w_c)."""
+def make_sequence(seed, settings, n_frames, max_t=0.012, max_rot_deg=0.6, hole_frac=0.03, bias=None):
+    """Smooth random-walk trajectory (TUM-like stand-in): list of (bgr, depth, ts, T_w_c).
+    bias: optional constant twist added every frame (e.g. a steady pan that forces new keyframes)."""
     rng = np.random.default_rng([seed, 23])
     scene = Scene(seed)
     k = (settings.width, settings.height, settings.fx, settings.fy, settings.cx, settings.cy)
@@ -183,7 +184,7 @@ def make_sequence(seed, settings, n_frames, max_t=0.012, max_rot_deg=0.6, hole_f
         vel = 0.85 * vel + 0.15 * random_twist(rng, max_t, max_rot_deg)
         # pull back towards the room centre so long sequences stay inside
         vel[:3] -= 0.02 * T[:3, :3].T @ T[:3, 3] * 0.05
-        T = T @ se3_exp(vel)
+        T = T @ se3_exp(vel if bias is None else vel + np.asarray(bias, np.float64))
     return frames
 
 

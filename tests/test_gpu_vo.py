@@ -1,0 +1,47 @@
+"""Sequential VO (REVO::start sequencing, system.cpp:84-305): product driver over the HIP path vs
+the oracle's restatement on the same synthetic sequence.  North-star bar: ATE of the HIP
+trajectory within 1 mm of the reference (= oracle) trajectory."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vo_matches_oracle_trajectory_and_keyframes():
+    from oracle import ro
+    from revo_amd import synth, vo
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    frames = synth.make_sequence(4, s, 45, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
+    gpu = vo.REVO(s)
+    cpu = ro.VO(s)
+    est_g, est_o, kf_g, kf_o = [], [], [], []
+    for i, (bgr, depth, ts, T) in enumerate(frames):
+        pg, kg = gpu.push(bgr, depth, ts)
+        po, ko = cpu.push(bgr, depth, ts)
+        est_g.append(pg)
+        est_o.append(po)
+        if kg:
+            kf_g.append(i)
+        if ko:
+            kf_o.append(i)
+    gt = [f[3] for f in frames]
+    assert kf_g == kf_o and len(kf_g) >= 3, (kf_g, kf_o)  # same keyframe decisions, and the path is exercised
+    assert gpu.nKeyFrames == cpu.num_keyframes()
+    d_rot = max(synth.rot_angle(a[:3, :3], b[:3, :3]) for a, b in zip(est_g, est_o))
+    d_tr = max(float(np.linalg.norm(a[:3, 3] - b[:3, 3])) for a, b in zip(est_g, est_o))
+    ate_go = synth.ate_rmse(est_g, est_o)  # HIP trajectory vs the reference (oracle) trajectory
+    ate_g, ate_o = synth.ate_rmse(est_g, gt), synth.ate_rmse(est_o, gt)
+    print("max per-frame diff %.2e rad %.2e m; ATE(gpu,oracle) %.2e m; ATE vs GT gpu %.4f oracle %.4f m"
+          % (d_rot, d_tr, ate_go, ate_g, ate_o))
+    assert ate_go < 1e-3
+    assert d_rot < 5e-4 and d_tr < 5e-4
+    assert abs(ate_g - ate_o) < 1e-3 and ate_g < 0.01
+    # the pipelined driver (one frame of look-ahead, like the reference's IO thread) gives the same bits
+    gpu2 = vo.REVO(s)
+    res2 = gpu2.run([(f[0], f[1], f[2]) for f in frames])
+    assert all(np.array_equal(a, b[0]) for a, b in zip(est_g, res2)) and gpu2.nKeyFrames == gpu.nKeyFrames
+    lines = gpu.tum_lines()  # system.cpp:76-80
+    assert len(lines) == len(frames) and len(lines[3].split()) == 8
+    q = np.array(lines[3].split()[4:], np.float64)
+    assert abs(np.linalg.norm(q) - 1) < 1e-5
