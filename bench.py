@@ -187,6 +187,15 @@ def main():
         tk += e1.elapsed_time(e2)
     ms_build, ms_trk_stage = tb / reps, tk / reps
 
+    # HBM traffic of k_track per launch from the PMC passes recorded under profiles/ (same workload;
+    # counters cannot be collected inside this process)
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc_file) and a.pairs == 32 and a.width == 640 and a.levels == 4:
+        try:
+            traffic = float(json.load(open(pmc_file))["k_track"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
     out = {
         "metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference",
         "value": world * a.pairs * a.steps / elapsed,
@@ -210,7 +219,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
             "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track,
         },
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},

@@ -343,3 +343,21 @@ def test_batch_matches_single_and_full_size_properties(api, ro):
     o_ref.makeKeyframe()
     r_o = ro.Tracker(s).trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
     assert rot_angle(res[0]["R"], r_o["R"]) < ROT_TOL and np.linalg.norm(res[0]["T"] - r_o["T"]) < TRANS_TOL
+
+
+def test_1280x960_five_levels(api, ro):
+    """BASELINE configs[3]: 1280x960, 5-level pyramid (levels >= 3 without histogram: the reference's
+    distPatchSizes has 3 entries)."""
+    s = ImgPyramidSettings.scaled(1280, 960, 5, hist_patch=(20, 10, 5, 0, 0, 0))
+    pair = synth.make_pair(21, s)
+    cam, g_ref, g_cur, o_ref, o_cur, gt, ot = _setup_pair(api, ro, s, pair)
+    compare_pyramid("big_ref", g_ref, o_ref, s, True)
+    compare_pyramid("big_cur", g_cur, o_cur, s, False)
+    st_g, R_g, T_g, err_g = gt.trackFrames(np.eye(3), np.zeros(3), g_ref, g_cur)
+    r_o = ot.trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
+    dr, dt = rot_angle(R_g, r_o["R"]), float(np.linalg.norm(T_g - r_o["T"]))
+    print("1280x960: GPU vs oracle %.2e rad %.2e m, evals gpu %s oracle %s, N0 %d"
+          % (dr, dt, gt.last_evals.tolist(), r_o["evals"].tolist(), g_cur.return3DEdges(0).shape[0]))
+    assert dr < ROT_TOL and dt < TRANS_TOL and st_g == r_o["status"]
+    er, et = synth.pose_error(R_g, T_g, pair["T_ref_curr"])
+    assert er < 2e-3 and et < 3e-3
