@@ -31,6 +31,7 @@ struct LevelGeom {
 };
 
 struct PyrGeom {
+  int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
   int total_tiles, total_pix, total_rows, total_cols, total_cc;
   float depth_min, depth_max;

@@ -35,8 +35,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ bgr, const float* __restrict__ depth_f32,
                                                     const uint16_t* __restrict__ depth_u16, float alpha,
-                                                    uint8_t* __restrict__ gray, float* __restrict__ depth_out, int npix) {
-  const int f = blockIdx.z;
+                                                    uint8_t* __restrict__ gray, float* __restrict__ depth_out, int npix, int frame0) {
+  const int f = frame0 + blockIdx.z;
   const int g4 = blockIdx.x * 256 + threadIdx.x;
   if (g4 * 4 >= npix) return;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(bgr + (size_t)f * npix * 3) + (size_t)g4 * 3;
@@ -71,10 +71,10 @@ __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ 
 #define PD_TW 32
 #define PD_TH 8
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
-                                                 int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst) {
+                                                 int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst, int frame0) {
   __shared__ uint8_t s_src[2 * PD_TH + 3][2 * PD_TW + 3 + 1];
   __shared__ int s_h[2 * PD_TH + 3][PD_TW + 1];
-  const int f = blockIdx.z;
+  const int f = frame0 + blockIdx.z;
   src += (size_t)f * sw * sh;
   dst += (size_t)f * dw * dh;
   dsrc += (size_t)f * sw * sh;
@@ -177,67 +177,112 @@ __device__ __forceinline__ void uf_unite(P* L, int a, int b) {
 // 8-connectivity of the candidates with a union-find in LDS; the global parent
 // array gets each pixel's tile-local root (as a global pixel index).
 // ---------------------------------------------------------------------------
+// LDS geometry (byte column bc = x - (x0 - 4), so the tile's pixels sit at bc = 4..67 and every
+// 4-pixel group is word aligned):
+//   s_gw  [20][19] words : gray rows y0-2 .. y0+17, bytes bc = 0..71 (replicated at the image border)
+//   s_mag [18][76] ints  : |grad|^2 rows y0-1 .. y0+16, columns bc = 0..71 (0 outside the image)
+//   s_dxy [18][76] ints  : dx | dy << 16
+#define NMS_GW 19
+#define NMS_MS 76
 __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
-  __shared__ uint8_t s_g[NMS_TILE_H + 4][NMS_TILE_W + 4 + 4];
-  __shared__ int s_mag[NMS_TILE_H + 2][NMS_TILE_W + 2 + 1];
-  __shared__ int s_dxy[NMS_TILE_H + 2][NMS_TILE_W + 2 + 1];
+  __shared__ uint32_t s_gw[NMS_TILE_H + 4][NMS_GW];
+  __shared__ __attribute__((aligned(16))) int s_mag[NMS_TILE_H + 2][NMS_MS];
+  __shared__ __attribute__((aligned(16))) int s_dxy[NMS_TILE_H + 2][NMS_MS];
   __shared__ int s_lab[NMS_TILE_H * NMS_TILE_W];
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
-  const LevelGeom lv = g.lv[l];
+  const LevelGeom& lv = g.lv[l];
   const int t = blockIdx.x - lv.tile_base;
   const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
   const int w = lv.w, h = lv.h;
   const uint8_t* gray = pl.gray[l] + (size_t)f * lv.npix;
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < (NMS_TILE_H + 4) * (NMS_TILE_W + 4); i += 256) {
-    const int r = i / (NMS_TILE_W + 4), c = i % (NMS_TILE_W + 4);
-    const int gy = clampi(y0 - 2 + r, 0, h - 1), gx = clampi(x0 - 2 + c, 0, w - 1);
-    s_g[r][c] = gray[(size_t)gy * w + gx];
+  // phase A: gray tile as aligned words (w is a multiple of 4, x0 of 64: a word is entirely inside
+  // or entirely outside the image; outside = BORDER_REPLICATE of the edge pixel)
+  for (int i = tid; i < (NMS_TILE_H + 4) * 18; i += 256) {
+    const int r = i / 18, wc = i - r * 18;
+    const int gy = clampi(y0 - 2 + r, 0, h - 1);
+    const int gx = x0 - 4 + 4 * wc;
+    uint32_t v;
+    if (gx < 0) v = 0x01010101u * gray[(size_t)gy * w];
+    else if (gx >= w) v = 0x01010101u * gray[(size_t)gy * w + w - 1];
+    else v = *reinterpret_cast<const uint32_t*>(gray + (size_t)gy * w + gx);
+    s_gw[r][wc] = v;
   }
   __syncthreads();
-  for (int i = tid; i < (NMS_TILE_H + 2) * (NMS_TILE_W + 2); i += 256) {
-    const int r = i / (NMS_TILE_W + 2), c = i % (NMS_TILE_W + 2);
-    const int ix = x0 - 1 + c, iy = y0 - 1 + r;
-    int mag = 0, dxy = 0;
-    if (ix >= 0 && ix < w && iy >= 0 && iy < h) {
-      const int a = s_g[r][c], b = s_g[r][c + 1], cc = s_g[r][c + 2];
-      const int d = s_g[r + 1][c], e = s_g[r + 1][c + 2];
-      const int p = s_g[r + 2][c], q = s_g[r + 2][c + 1], rr = s_g[r + 2][c + 2];
-      const int dx = (cc + 2 * e + rr) - (a + 2 * d + p);
-      const int dy = (p + 2 * q + rr) - (a + 2 * b + cc);
-      mag = dx * dx + dy * dy;
-      dxy = (int)(((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16));
+  // phase B: Sobel 3x3 + L2 magnitude, 4 adjacent positions per task from 9 word reads
+  for (int i = tid; i < (NMS_TILE_H + 2) * 18; i += 256) {
+    const int r = i / 18, c = i - r * 18;
+    const int iy = y0 - 1 + r;
+    // bytes bc = 4c-1 .. 4c+4 of gray rows r, r+1, r+2
+    uint32_t lo[3], mid[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = c > 0 ? s_gw[r + k][c - 1] : 0u;
+      mid[k] = s_gw[r + k][c];
+      hi[k] = c < 17 ? s_gw[r + k][c + 1] : 0u;
     }
-    s_mag[r][c] = mag;
-    s_dxy[r][c] = dxy;
+    int mg[4], dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // neighbours of byte j of `mid`: left = byte j-1 (or byte 3 of lo), right = byte j+1 (or byte 0 of hi)
+      int L3[3], C3[3], R3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        L3[k] = j == 0 ? (int)(lo[k] >> 24) : (int)((mid[k] >> (8 * (j - 1))) & 255u);
+        C3[k] = (int)((mid[k] >> (8 * j)) & 255u);
+        R3[k] = j == 3 ? (int)(hi[k] & 255u) : (int)((mid[k] >> (8 * (j + 1))) & 255u);
+      }
+      const int dx = (R3[0] + 2 * R3[1] + R3[2]) - (L3[0] + 2 * L3[1] + L3[2]);
+      const int dy = (L3[2] + 2 * C3[2] + R3[2]) - (L3[0] + 2 * C3[0] + R3[0]);
+      const int ix = x0 - 4 + 4 * c + j;
+      const bool inside = ix >= 0 && ix < w && iy >= 0 && iy < h;
+      mg[j] = inside ? dx * dx + dy * dy : 0;
+      dq[j] = inside ? (int)(((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16)) : 0;
+    }
+    *reinterpret_cast<int4*>(&s_mag[r][4 * c]) = make_int4(mg[0], mg[1], mg[2], mg[3]);
+    *reinterpret_cast<int4*>(&s_dxy[r][4 * c]) = make_int4(dq[0], dq[1], dq[2], dq[3]);
   }
   __syncthreads();
 
+  // phase C: non-maximum suppression, 4 adjacent pixels per thread
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
   const int lx0 = (tid % 16) * 4, ly = tid / 16;
+  const int bc0 = lx0 + 4;  // byte column of the first pixel
+  int mrow[3][6];           // magnitudes of rows ly, ly+1, ly+2 (mag-row coords), columns bc0-1 .. bc0+4
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int4 m4 = *reinterpret_cast<const int4*>(&s_mag[ly + k][bc0]);
+    mrow[k][0] = s_mag[ly + k][bc0 - 1];
+    mrow[k][1] = m4.x; mrow[k][2] = m4.y; mrow[k][3] = m4.z; mrow[k][4] = m4.w;
+    mrow[k][5] = s_mag[ly + k][bc0 + 4];
+  }
+  const int4 d4 = *reinterpret_cast<const int4*>(&s_dxy[ly + 1][bc0]);
+  const int dxy4[4] = {d4.x, d4.y, d4.z, d4.w};
   int cand[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int lx = lx0 + k;
-    const int m = s_mag[ly + 1][lx + 1];
+    const int m = mrow[1][k + 1];
     int val = 0;
     if (m > g.canny_low) {
-      const int dxy = s_dxy[ly + 1][lx + 1];
+      const int dxy = dxy4[k];
       const int xs = (int)(int16_t)(dxy & 0xffff), ys = dxy >> 16;
       const int ax = abs(xs), ay = abs(ys) << 15;
       const int tg22x = ax * TG22;
       bool is_max;
       if (ay < tg22x) {
-        is_max = m > s_mag[ly + 1][lx] && m >= s_mag[ly + 1][lx + 2];
+        is_max = m > mrow[1][k] && m >= mrow[1][k + 2];
       } else {
         const int tg67x = tg22x + (ax << 16);
         if (ay > tg67x) {
-          is_max = m > s_mag[ly][lx + 1] && m >= s_mag[ly + 2][lx + 1];
+          is_max = m > mrow[0][k + 1] && m >= mrow[2][k + 1];
         } else {
-          const int s = (xs ^ ys) < 0 ? -1 : 1;
-          is_max = m > s_mag[ly][lx + 1 - s] && m > s_mag[ly + 2][lx + 1 + s];
+          const bool neg = (xs ^ ys) < 0;  // s = -1: up-right / down-left; s = +1: up-left / down-right
+          const int mu = neg ? mrow[0][k + 2] : mrow[0][k];
+          const int md = neg ? mrow[2][k] : mrow[2][k + 2];
+          is_max = m > mu && m > md;
         }
       }
       if (is_max) val = (m > g.canny_high) ? 2 : 1;
@@ -245,19 +290,38 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     const bool inside = (x0 + lx < w) && (y0 + ly < h);
     if (!inside) val = 0;
     cand[k] = val;
-    s_lab[ly * NMS_TILE_W + lx] = val ? ly * NMS_TILE_W + lx : -1;
+  }
+  // Run-based initialisation: a row of the tile is handled by 16 consecutive lanes, so its 64-bit
+  // candidate mask is an OR-butterfly over those lanes; every candidate starts with the FIRST
+  // pixel of its horizontal run as parent.  Horizontal connectivity then needs no unions at all
+  // (a 64-pixel horizontal edge used to build a 64-hop LDS chain that every later find walked),
+  // and the vertical links below produce chains bounded by the 16 rows of the tile.
+  {
+    unsigned long long rm = (unsigned long long)((cand[0] ? 1 : 0) | (cand[1] ? 2 : 0) | (cand[2] ? 4 : 0) | (cand[3] ? 8 : 0))
+                            << lx0;
+    rm |= __shfl_xor(rm, 1);
+    rm |= __shfl_xor(rm, 2);
+    rm |= __shfl_xor(rm, 4);
+    rm |= __shfl_xor(rm, 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lx0 + k;
+      const unsigned long long zeros_below = ~rm & ((1ull << c) - 1ull);
+      const int start = zeros_below ? 64 - __clzll((long long)zeros_below) : 0;
+      s_lab[ly * NMS_TILE_W + c] = cand[k] ? ly * NMS_TILE_W + start : -1;
+    }
   }
   __syncthreads();
-  // tile-local 8-connectivity: unite with W, NW, N, NE inside the tile
+  // vertical links: N if it is a candidate (then NW / NE belong to N's run), otherwise NW and NE
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (!cand[k]) continue;
+    if (!cand[k] || ly == 0) continue;
     const int lx = lx0 + k;
     const int me = ly * NMS_TILE_W + lx;
-    if (lx > 0 && s_lab[me - 1] >= 0) uf_unite(s_lab, me, me - 1);
-    if (ly > 0) {
+    if (s_lab[me - NMS_TILE_W] >= 0) {
+      uf_unite(s_lab, me, me - NMS_TILE_W);
+    } else {
       if (lx > 0 && s_lab[me - NMS_TILE_W - 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W - 1);
-      if (s_lab[me - NMS_TILE_W] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W);
       if (lx < NMS_TILE_W - 1 && s_lab[me - NMS_TILE_W + 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W + 1);
     }
   }
@@ -314,7 +378,7 @@ __device__ __forceinline__ bool ccl_chunk(const PyrGeom& g, int chunk, int* l_ou
 
 // a5 (second half, 1/3): unite candidates across tile borders (global memory).
 __global__ void __launch_bounds__(256) k_ccl_border(PyrGeom g, FramePlanes pl) {
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   int l, p0;
   if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
   const LevelGeom& lv = g.lv[l];
@@ -345,7 +409,7 @@ __global__ void __launch_bounds__(256) k_ccl_border(PyrGeom g, FramePlanes pl) {
 // root (so every pixel is <= 2 hops away afterwards) and hands its tile-level "holds a
 // strong pixel" bit to that root.
 __global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   int l, p0;
   if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
   const LevelGeom& lv = g.lv[l];
@@ -368,7 +432,7 @@ __global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
 // a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes
 // edgesPyr and its clone edgesOrigPyr (imgpyramidrgbd.cpp:185-186).
 __global__ void __launch_bounds__(256) k_ccl_out(PyrGeom g, FramePlanes pl) {
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   int l, p0;
   if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
   const LevelGeom& lv = g.lv[l];
@@ -398,7 +462,7 @@ __global__ void __launch_bounds__(256) k_ccl_out(PyrGeom g, FramePlanes pl) {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_hist(PyrGeom g, FramePlanes pl, int rows_total) {
   __shared__ int s_cnt[128];
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   // decode (level, tile row) over the levels that have a histogram
   int l = -1, ty = blockIdx.x;
   for (int k = 0; k < g.n_levels; ++k) {
@@ -445,7 +509,7 @@ __global__ void __launch_bounds__(256) k_hist(PyrGeom g, FramePlanes pl, int row
 // the already-filled level l-1, so one 1024-thread block per frame walks the
 // levels in order.
 __global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   for (int l = 1; l < g.n_levels; ++l) {
     const LevelGeom lv = g.lv[l], lf = g.lv[l - 1];
     if (!(g.use_edge_hist && lv.patch > 0 && lf.patch > 0)) continue;
@@ -485,7 +549,7 @@ __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl) {
-  const int f = blockIdx.z;
+  const int f = g.frame0 + blockIdx.z;
   const int l = blockIdx.y;  // block-uniform level
   const LevelGeom& lv = g.lv[l];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -519,7 +583,7 @@ __global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl)
 
 __global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl) {
   __shared__ int s_part[1024];
-  const int f = blockIdx.z, l = blockIdx.x;
+  const int f = g.frame0 + blockIdx.z, l = blockIdx.x;
   const LevelGeom lv = g.lv[l];
   const int n = lv.w * lv.nchunk;
   int* a = pl.chunk[l] + (size_t)f * n;
@@ -687,7 +751,7 @@ void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_
   const int npix = g.lv[0].npix;
   dim3 grid((npix / 4 + 255) / 256, 1, B);
   hipLaunchKernelGGL(k_gray_depth, grid, dim3(256), 0, s, d_bgr, d_depth_f32, d_depth_u16, u16_alpha, p.gray[0],
-                     p.depth[0], npix);
+                     p.depth[0], npix, g.frame0);
 }
 
 void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s) {
@@ -695,7 +759,7 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
   const LevelGeom& sl = g.lv[lvl - 1];
   dim3 grid((d.w + PD_TW - 1) / PD_TW, (d.h + PD_TH - 1) / PD_TH, B);
   hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h,
-                     p.depth[lvl - 1], p.depth[lvl]);
+                     p.depth[lvl - 1], p.depth[lvl], g.frame0);
 }
 
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
@@ -714,7 +778,7 @@ void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
   for (int l = 0; l < g.n_levels; ++l)
     if (g.lv[l].patch > 0) rows += g.lv[l].hist_h;
   if (rows == 0) return;
-  hipMemsetAsync(p.hist_nz, 0, sizeof(int) * REVO_L * B, s);
+  hipMemsetAsync(p.hist_nz + (size_t)g.frame0 * REVO_L, 0, sizeof(int) * REVO_L * B, s);
   hipLaunchKernelGGL(k_hist, dim3(rows, 1, B), dim3(256), 0, s, g, p, rows);
   if (g.use_edge_hist && g.n_levels > 1) hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p);
 }
