@@ -117,6 +117,20 @@ __device__ __forceinline__ bool is_orthogonal(const float* R) {  // rotation_mat
   return sqrtf(n2) < 1e-5f && det > 0.0f;
 }
 
+// sin / cos for the LM increments (|x| is ~1e-2 .. 1e-1): below 0.5 rad the truncated series are
+// accurate to float rounding (next terms x^11/11! < 2e-11, x^10/10! < 3e-10 relative) and avoid the
+// full-range argument reduction of sinf/cosf on the serial path; larger angles take the library path.
+__device__ __forceinline__ float sin_lm(float x) {
+  if (fabsf(x) > 0.5f) return sinf(x);
+  const float x2 = x * x;
+  return x * (1.0f + x2 * (-1.0f / 6.0f + x2 * (1.0f / 120.0f + x2 * (-1.0f / 5040.0f + x2 * (1.0f / 362880.0f)))));
+}
+__device__ __forceinline__ float cos_lm(float x) {
+  if (fabsf(x) > 0.5f) return cosf(x);
+  const float x2 = x * x;
+  return 1.0f + x2 * (-0.5f + x2 * (1.0f / 24.0f + x2 * (-1.0f / 720.0f + x2 * (1.0f / 40320.0f))));
+}
+
 // Sophus::SE3f::exp(inc) * (q,t)  (se3.hpp:723-745, so3.hpp:531-565, se3.hpp:317-321, so3.hpp:335-352)
 __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, const float* t, float* qo, float* to) {
   const float ox = a[3], oy = a[4], oz = a[5];
@@ -136,8 +150,8 @@ __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, cons
     real = 1.0f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * p4;
   } else {
     const float h = 0.5f * theta;
-    imag = __fdiv_rn(sinf(h), theta);
-    real = cosf(h);
+    imag = __fdiv_rn(sin_lm(h), theta);
+    real = cos_lm(h);
   }
   const float qe[4] = {real, imag * ox, imag * oy, imag * oz};
   if (theta < 1e-5f) {
@@ -148,8 +162,8 @@ __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, cons
 #pragma unroll
       for (int c = 0; c < 3; ++c) V[r * 3 + c] = Rm[c * 3 + r];
   } else {
-    const float ca = __fdiv_rn(1.0f - cosf(theta), theta_sq);
-    const float cb = __fdiv_rn(theta - sinf(theta), theta_sq * theta);
+    const float ca = __fdiv_rn(1.0f - cos_lm(theta), theta_sq);
+    const float cb = __fdiv_rn(theta - sin_lm(theta), theta_sq * theta);
 #pragma unroll
     for (int i = 0; i < 9; ++i) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * O[i]) + cb * O2[i];
   }
@@ -455,10 +469,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
     for (int i = 0; i < 3; ++i) Tp[i] = T0[i];
     if (prm.eval_only) {
       phase = PH_EVAL_ONLY;
-    } else if (!is_orthogonal(R0)) {  // Sophus::SE3f(R,T) would abort, optimizer.cpp:241
-      flags = 2;
-      mode = MODE_DONE;
-    } else if (prm.check_init) {
+    } else if (prm.check_init) {  // tracker.cpp:314 runs BEFORE Sophus::SE3f(R,T) (optimizer.cpp:241)
       mode = MODE_COST; phase = PH_COST_EYE; level = prm.pyr_min_lvl;
 #pragma unroll
       for (int i = 0; i < 9; ++i) Rp[i] = (i % 4 == 0) ? 1.0f : 0.0f;
@@ -484,6 +495,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
       for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rp[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) s_ctrl.T[i] = Tp[i];
+      if (!prm.eval_only && !prm.check_init && !is_orthogonal(R0)) {  // Sophus::SE3f(R,T) would abort
+        s.flags = 2;
+        mode = MODE_DONE;
+      }
       s_ctrl.level = level;
       s_ctrl.mode = mode;
     }
@@ -624,6 +639,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
           phase = PH_LEVEL_FIRST;
           next_mode = MODE_EVAL;
           next_level = prm.lvl_begin;
+          if (!is_orthogonal(Rs)) { flags |= 2; next_mode = MODE_DONE; }  // Sophus::SE3f(R,T), optimizer.cpp:241
           if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rs[i];

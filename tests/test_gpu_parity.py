@@ -265,8 +265,15 @@ def test_error_behaviour(api, pair640):
     a.makeKeyframe()
     Rbad = np.eye(3)
     Rbad[0, 1] = 0.01
+    # tracker.cpp:314 runs the init check first: a bad prior that loses to identity is reset and tracked
+    st, R, T, err = trk.trackFrames(Rbad, np.zeros(3), a, b)
+    assert np.isfinite(err)
+    trk2 = api.TrackerNew(TrackerSettings(check_init_values=0), s, cam)
     with pytest.raises(api.RevoError) as e:  # Sophus SO3(R) ENSURE -> abort() in the reference
-        trk.trackFrames(Rbad, np.zeros(3), a, b)
+        trk2.trackFrames(Rbad, np.zeros(3), a, b)
+    assert e.value.code == -4
+    with pytest.raises(api.RevoError) as e:  # Optimizer::trackFrames builds SE3f(R,T) directly
+        trk2.mOptimizer.trackFrames(a, b, Rbad, np.zeros(3), 1)
     assert e.value.code == -4
     with pytest.raises(api.RevoError):
         a.returnGray(7)
