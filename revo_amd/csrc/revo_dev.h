@@ -55,6 +55,7 @@ struct FramePlanes {
   float4* table[REVO_L];       // optimizationStructure
   uint8_t* hist[REVO_L];       // histPyr (frame stride hist_w*hist_h)
   int* chunk[REVO_L];          // compaction counts -> offsets (frame stride w*nchunk)
+  unsigned* cmask[REVO_L];     // per (column, 32-row chunk): bit y = edge pixel with valid depth
   int* npts;                   // [B][REVO_L]
   int* hist_nz;                // [B][REVO_L]
 };

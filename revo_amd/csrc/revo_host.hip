@@ -135,7 +135,9 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   const int L = s.pyr_min_lvl - s.pyr_max_lvl + 1;  // camerapyr.h:68-71
   if (s.pyr_max_lvl != 0) { *why = "pyr_max_lvl must be 0 (the reference indexes per-level vectors by level)"; return -1; }
   if (L < 1 || L > REVO_L) { *why = "1..6 pyramid levels supported"; return -1; }
-  if (s.width <= 0 || s.height <= 0 || s.width > REVO_MAX_WIDTH) { *why = "bad image size"; return -1; }
+  if (s.width <= 0 || s.height <= 0 || s.width > REVO_MAX_WIDTH || s.height > 1024) {
+    *why = "image size must be within 2048 x 1024"; return -1;
+  }
   if (s.width % (4 << (L - 1)) || s.height % (1 << (L - 1))) {
     *why = "width must be a multiple of 4*2^(levels-1) and height of 2^(levels-1)"; return -1;
   }
@@ -241,6 +243,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       fs->p.table[l] = (float4*)take(n * 16);
       fs->p.hist[l] = (uint8_t*)take((size_t)std::max(1, v.hist_w * v.hist_h) * B);
       fs->p.chunk[l] = (int*)take((size_t)v.w * v.nchunk * B * 4);
+      fs->p.cmask[l] = (unsigned*)take((size_t)v.w * v.nchunk * B * 4);
     }
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.hist_nz = (int*)take(sizeof(int) * REVO_L * B);

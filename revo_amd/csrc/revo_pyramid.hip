@@ -376,32 +376,36 @@ __device__ __forceinline__ bool ccl_chunk(const PyrGeom& g, int chunk, int* l_ou
   return true;
 }
 
-// a5 (second half, 1/3): unite candidates across tile borders (global memory).
-__global__ void __launch_bounds__(256) k_ccl_border(PyrGeom g, FramePlanes pl) {
+// a5 (second half, 1/3): unite candidates across tile borders (global memory).  One block per
+// NMS tile, one thread per BORDER pixel of the tile (top row, left column, right column): the
+// unions of a horizontal edge lying on a tile's top row run in parallel instead of 48 in a row
+// inside one thread.
+__global__ void __launch_bounds__(128) k_ccl_border(PyrGeom g, FramePlanes pl) {
   const int f = g.frame0 + blockIdx.z;
-  int l, p0;
-  if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
+  const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
   const LevelGeom& lv = g.lv[l];
-  const int w = lv.w;
+  const int t = blockIdx.x - lv.tile_base;
+  const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
+  const int w = lv.w, h = lv.h;
+  const int tid = threadIdx.x;
+  int lx, ly;
+  if (tid < 64) { lx = tid; ly = 0; }
+  else if (tid < 80) { lx = 0; ly = tid - 64; }
+  else if (tid < 96) { lx = NMS_TILE_W - 1; ly = tid - 80; }
+  else return;
+  if (tid >= 64 && ly == 0) return;  // the corners belong to the top row
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= w || y >= h) return;
   const uint8_t* nmsp = pl.nms[l] + (size_t)f * lv.npix;
-  const uint4 m4 = *reinterpret_cast<const uint4*>(nmsp + p0);
-  if (((m4.x | m4.y | m4.z | m4.w) & 0x03030303u) == 0) return;
+  const int p = y * w + x;
+  if ((nmsp[p] & 3) == 0) return;
   int* L = pl.scratch[l] + (size_t)f * lv.npix;
-  const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (((mw[k >> 2] >> (8 * (k & 3))) & 3) == 0) continue;
-    const int p = p0 + k;
-    const int x = p % w, y = p / w;
-    const int lx = x % NMS_TILE_W, lyy = y % NMS_TILE_H;
-    if (lx != 0 && lyy != 0 && lx != NMS_TILE_W - 1) continue;
-    // neighbours that live in another tile
-    if (lx == 0 && x > 0 && (nmsp[p - 1] & 3)) uf_unite_global(L, p, p - 1);
-    if (y > 0) {
-      if ((lx == 0 || lyy == 0) && x > 0 && (nmsp[p - w - 1] & 3)) uf_unite_global(L, p, p - w - 1);
-      if (lyy == 0 && (nmsp[p - w] & 3)) uf_unite_global(L, p, p - w);
-      if ((lx == NMS_TILE_W - 1 || lyy == 0) && x < w - 1 && (nmsp[p - w + 1] & 3)) uf_unite_global(L, p, p - w + 1);
-    }
+  // neighbours that live in another tile
+  if (lx == 0 && x > 0 && (nmsp[p - 1] & 3)) uf_unite_global(L, p, p - 1);
+  if (y > 0) {
+    if ((lx == 0 || ly == 0) && x > 0 && (nmsp[p - w - 1] & 3)) uf_unite_global(L, p, p - w - 1);
+    if (ly == 0 && (nmsp[p - w] & 3)) uf_unite_global(L, p, p - w);
+    if ((lx == NMS_TILE_W - 1 || ly == 0) && x < w - 1 && (nmsp[p - w + 1] & 3)) uf_unite_global(L, p, p - w + 1);
   }
 }
 
@@ -556,27 +560,32 @@ __global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl)
   if (i >= lv.w * lv.nchunk) return;
   const int x = i % lv.w, c = i / lv.w;  // adjacent threads walk adjacent columns
   const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
-  const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
   const float* depth = pl.depth[l] + (size_t)f * lv.npix;
-  int* slot = pl.chunk[l] + (size_t)f * lv.w * lv.nchunk + (size_t)x * lv.nchunk + c;
+  const size_t slot_i = (size_t)f * lv.w * lv.nchunk + (size_t)x * lv.nchunk + c;  // column-major chunk order
   if (!WRITE) {
-    int n = 0;
+    // count: the depth plane is only touched where there is an edge (~8 % of the pixels); the
+    // validity of the 32 rows is kept as a bit mask for the write pass
+    const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
+    unsigned em = 0;
 #pragma unroll 8
-    for (int y = yb; y < ye; ++y) {
-      const float Z = depth[(size_t)y * lv.w + x];
-      n += (edges[(size_t)y * lv.w + x] > 0 && depth_ok(Z, g.depth_min, g.depth_max)) ? 1 : 0;
+    for (int y = yb; y < ye; ++y) em |= (edges[(size_t)y * lv.w + x] ? 1u : 0u) << (y - yb);
+    unsigned vm = 0;
+    for (unsigned m = em; m; m &= m - 1) {
+      const int b = __ffs(m) - 1;
+      const float Z = depth[(size_t)(yb + b) * lv.w + x];
+      if (depth_ok(Z, g.depth_min, g.depth_max)) vm |= 1u << b;
     }
-    *slot = n;
+    pl.cmask[l][slot_i] = vm;
+    pl.chunk[l][slot_i] = __popc(vm);
   } else {
-    int o = *slot;
+    int o = pl.chunk[l][slot_i];
     float4* out = pl.pts[l] + (size_t)f * lv.npix;
-    for (int y = yb; y < ye; ++y) {
+    for (unsigned m = pl.cmask[l][slot_i]; m; m &= m - 1) {
+      const int y = yb + __ffs(m) - 1;
       const float Z = depth[(size_t)y * lv.w + x];
-      if (edges[(size_t)y * lv.w + x] > 0 && depth_ok(Z, g.depth_min, g.depth_max)) {
-        const float X = __fdiv_rn(Z * ((float)x - lv.cx), lv.fx);
-        const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
-        out[o++] = make_float4(X, Y, Z, 1.0f);
-      }
+      const float X = __fdiv_rn(Z * ((float)x - lv.cx), lv.fx);
+      const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
+      out[o++] = make_float4(X, Y, Z, 1.0f);
     }
   }
 }
@@ -614,50 +623,52 @@ __global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl
 // to OpenCV's (all d2 < 2^24); no edge at all -> OpenCV's 1e15f sentinel.
 // ---------------------------------------------------------------------------
 #define EDT_INF (1 << 29)
-#define EDT_STRIP 64   // columns per block
-#define EDT_GROUPS 16  // row groups per column -> 64 x 16 = 1024 threads, chains of h/16 rows
-__global__ void __launch_bounds__(EDT_STRIP * EDT_GROUPS) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride) {
-  __shared__ int s_first[EDT_GROUPS][EDT_STRIP];  // first edge row of the group's segment (or +INF)
-  __shared__ int s_last[EDT_GROUPS][EDT_STRIP];   // last edge row of the segment (or -INF)
+// 1024 threads = (columns of the strip) x (row groups); every thread owns <= 32 rows of one column and
+// keeps their edge bits in a 32-bit mask: nearest edge above/below = clz / ffs on the mask, or the
+// LDS carry (last/first edge row of the other groups).  One edge read, one g^2 write per pixel.
+#define EDT_THREADS 1024
+__global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+  __shared__ int s_first[EDT_THREADS];  // [group][column]: first edge row of the group's segment (or +INF)
+  __shared__ int s_last[EDT_THREADS];   // last edge row of the segment (or -INF)
   const int f = f0 + blockIdx.z * fstride;
-  // decode (level, strip)
-  int l = 0, sidx = blockIdx.x;
+  // decode (level, strip); taller levels use 32 groups x 32 columns, the others 16 x 64
+  int l = 0, sidx = blockIdx.x, ngroups = 16, ncols = 64;
   for (int k = 0; k < g.n_levels; ++k) {
-    const int ns = (g.lv[k].w + EDT_STRIP - 1) / EDT_STRIP;
+    ngroups = g.lv[k].h > 512 ? 32 : 16;
+    ncols = EDT_THREADS / ngroups;
+    const int ns = (g.lv[k].w + ncols - 1) / ncols;
     if (sidx < ns) { l = k; break; }
     sidx -= ns;
   }
-  const LevelGeom lv = g.lv[l];
-  const int col = threadIdx.x % EDT_STRIP, grp = threadIdx.x / EDT_STRIP;
-  const int x = sidx * EDT_STRIP + col;
-  const int rpg = (lv.h + EDT_GROUPS - 1) / EDT_GROUPS;
+  const LevelGeom& lv = g.lv[l];
+  const int col = threadIdx.x % ncols, grp = threadIdx.x / ncols;
+  const int x = sidx * ncols + col;
+  const int rpg = (lv.h + ngroups - 1) / ngroups;  // <= 32 (height <= 1024)
   const int yb = min(lv.h, grp * rpg), ye = min(lv.h, yb + rpg);
   const bool in = x < lv.w;
   const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
-  int* g2 = pl.scratch[l] + (size_t)f * lv.npix;
-  int first = EDT_INF, last = -EDT_INF;
-  if (in)
-    for (int y = yb; y < ye; ++y)
-      if (edges[(size_t)y * lv.w + x]) { first = min(first, y); last = y; }
-  s_first[grp][col] = first;
-  s_last[grp][col] = last;
+  unsigned em = 0;
+  if (in) {
+#pragma unroll 8
+    for (int y = yb; y < ye; ++y) em |= (edges[(size_t)y * lv.w + x] ? 1u : 0u) << (y - yb);
+  }
+  s_first[grp * ncols + col] = em ? yb + __ffs(em) - 1 : EDT_INF;
+  s_last[grp * ncols + col] = em ? yb + 31 - __clz(em) : -EDT_INF;
   __syncthreads();
   if (!in) return;
   int above = -EDT_INF, below = EDT_INF;  // nearest edge rows outside this segment
-  for (int k = 0; k < grp; ++k) above = max(above, s_last[k][col]);
-  for (int k = EDT_GROUPS - 1; k > grp; --k) below = min(below, s_first[k][col]);
-  // downward walk: distance to the nearest edge at or above y
-  int up = above;
+  for (int k = 0; k < grp; ++k) above = max(above, s_last[k * ncols + col]);
+  for (int k = ngroups - 1; k > grp; --k) below = min(below, s_first[k * ncols + col]);
+  int* g2 = pl.scratch[l] + (size_t)f * lv.npix;
   for (int y = yb; y < ye; ++y) {
-    if (edges[(size_t)y * lv.w + x]) up = y;
-    g2[(size_t)y * lv.w + x] = (up <= -EDT_INF) ? EDT_INF : (y - up);
-  }
-  // upward walk: combine with the nearest edge at or below y, square
-  int dn = below;
-  for (int y = ye - 1; y >= yb; --y) {
-    if (edges[(size_t)y * lv.w + x]) dn = y;
+    const int k = y - yb;
+    const unsigned lo = em & (0xffffffffu >> (31 - k));  // bits 0..k: edges at or above y (inside the segment)
+    const unsigned hi = em >> k;                          // bit 0 = row y: edges at or below y
+    const int up = lo ? yb + 31 - __clz(lo) : above;
+    const int dn = hi ? y + __ffs(hi) - 1 : below;
+    const int d_up = (up <= -EDT_INF) ? EDT_INF : (y - up);
     const int d_dn = (dn >= EDT_INF) ? EDT_INF : (dn - y);
-    const int m = min(d_dn, g2[(size_t)y * lv.w + x]);
+    const int m = min(d_up, d_dn);
     g2[(size_t)y * lv.w + x] = m >= EDT_INF ? EDT_INF : m * m;
   }
 }
@@ -768,7 +779,7 @@ void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 
 void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid((g.lv[0].npix / 16 + 255) / 256, g.n_levels, B);
-  hipLaunchKernelGGL(k_ccl_border, grid, dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_ccl_border, dim3(g.total_tiles, 1, B), dim3(128), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_out, grid, dim3(256), 0, s, g, p);
 }
@@ -792,8 +803,11 @@ void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s
 
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {
   int strips = 0;
-  for (int l = 0; l < g.n_levels; ++l) strips += (g.lv[l].w + EDT_STRIP - 1) / EDT_STRIP;
-  hipLaunchKernelGGL(k_edt_cols, dim3(strips, 1, count), dim3(EDT_STRIP * EDT_GROUPS), 0, s, g, p, f0, fstride);
+  for (int l = 0; l < g.n_levels; ++l) {
+    const int ncols = EDT_THREADS / (g.lv[l].h > 512 ? 32 : 16);
+    strips += (g.lv[l].w + ncols - 1) / ncols;
+  }
+  hipLaunchKernelGGL(k_edt_cols, dim3(strips, 1, count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride);
   hipLaunchKernelGGL(k_edt_rows, dim3(g.total_rows, 1, count), dim3(256), 0, s, g, p, f0, fstride);
 }
 
