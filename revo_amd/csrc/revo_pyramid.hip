@@ -433,31 +433,32 @@ __global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
   }
 }
 
-// a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes
-// edgesPyr and its clone edgesOrigPyr (imgpyramidrgbd.cpp:185-186).
+// a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes edgesPyr and its clone
+// edgesOrigPyr (imgpyramidrgbd.cpp:185-186).  4 pixels per thread: the first hop of all four is
+// ONE coalesced 16-byte load of the parents the NMS kernel wrote for this group; after k_ccl_flag
+// the second hop lands on the global root.
 __global__ void __launch_bounds__(256) k_ccl_out(PyrGeom g, FramePlanes pl) {
   const int f = g.frame0 + blockIdx.z;
-  int l, p0;
-  if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
+  const int l = blockIdx.y;
   const LevelGeom& lv = g.lv[l];
+  const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= lv.npix) return;
   const uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
-  const uint4 m4 = *reinterpret_cast<const uint4*>(nms + p0);
-  uint32_t ow[4] = {0u, 0u, 0u, 0u};
-  if ((m4.x | m4.y | m4.z | m4.w) & 0x03030303u) {
-    const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
+  const uint32_t m = *reinterpret_cast<const uint32_t*>(nms + p0);
+  uint32_t o = 0;
+  if (m & 0x03030303u) {
     const int* L = pl.scratch[l] + (size_t)f * lv.npix;
-    // (a hop-synchronous variant that issues all 16 lookups of a hop together measured slower,
-    // 138 vs 84 us: the pass is bound by the count of scattered transactions, not by the chain)
+    const int4 lab = *reinterpret_cast<const int4*>(L + p0);
+    const int tl[4] = {lab.x, lab.y, lab.z, lab.w};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (((mw[k >> 2] >> (8 * (k & 3))) & 3) == 0) continue;
-      const int r = uf_find_final(L, p0 + k);
-      if (nms[r] & 4) ow[k >> 2] |= 0xffu << (8 * (k & 3));
+    for (int k = 0; k < 4; ++k) {
+      if (((m >> (8 * k)) & 3u) == 0) continue;
+      const int r = uf_find_final(L, tl[k]);
+      if (nms[r] & 4) o |= 0xffu << (8 * k);
     }
   }
-  const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-  *reinterpret_cast<uint4*>(pl.edges[l] + (size_t)f * lv.npix + p0) = o;
-  *reinterpret_cast<uint4*>(pl.edges_orig[l] + (size_t)f * lv.npix + p0) = o;
+  *reinterpret_cast<uint32_t*>(pl.edges[l] + (size_t)f * lv.npix + p0) = o;
+  *reinterpret_cast<uint32_t*>(pl.edges_orig[l] + (size_t)f * lv.npix + p0) = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -687,11 +688,13 @@ __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int
   float* dt = pl.dt[l] + (size_t)f * lv.npix + (size_t)y * w;
   for (int x = threadIdx.x; x < w; x += 256) {
     int best = s_g2[x];
-    for (int d = 1; d < w; ++d) {
+    for (int d = 1; d < w; d += 2) {  // two distances per trip: four independent LDS reads, one dependent min chain
       const int dd = d * d;
       if (dd >= best) break;
-      if (x - d >= 0) best = min(best, dd + s_g2[x - d]);
-      if (x + d < w) best = min(best, dd + s_g2[x + d]);
+      const int d1 = d + 1, dd1 = d1 * d1;
+      const int a0 = (x - d >= 0) ? s_g2[x - d] : EDT_INF, b0 = (x + d < w) ? s_g2[x + d] : EDT_INF;
+      const int a1 = (x - d1 >= 0) ? s_g2[x - d1] : EDT_INF, b1 = (x + d1 < w) ? s_g2[x + d1] : EDT_INF;
+      best = min(best, min(min(dd + a0, dd + b0), min(dd1 + a1, dd1 + b1)));
     }
     dt[x] = best >= EDT_INF ? sqrtf(1e15f) : sqrtf((float)best);
   }
@@ -781,7 +784,7 @@ void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid((g.lv[0].npix / 16 + 255) / 256, g.n_levels, B);
   hipLaunchKernelGGL(k_ccl_border, dim3(g.total_tiles, 1, B), dim3(128), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
-  hipLaunchKernelGGL(k_ccl_out, grid, dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_ccl_out, dim3((g.lv[0].npix / 4 + 255) / 256, g.n_levels, B), dim3(256), 0, s, g, p);
 }
 
 void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
