@@ -246,59 +246,60 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   }
   __syncthreads();
 
-  // phase C: non-maximum suppression, 4 adjacent pixels per thread
+  // phase C: non-maximum suppression, 4 adjacent pixels per thread and pass (a pass = 16 tile rows)
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
-  const int lx0 = (tid % 16) * 4, ly = tid / 16;
+  const int lx0 = (tid % 16) * 4;
   const int bc0 = lx0 + 4;  // byte column of the first pixel
-  int mrow[3][6];           // magnitudes of rows ly, ly+1, ly+2 (mag-row coords), columns bc0-1 .. bc0+4
+  int cand[NMS_PASSES][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int4 m4 = *reinterpret_cast<const int4*>(&s_mag[ly + k][bc0]);
-    mrow[k][0] = s_mag[ly + k][bc0 - 1];
-    mrow[k][1] = m4.x; mrow[k][2] = m4.y; mrow[k][3] = m4.z; mrow[k][4] = m4.w;
-    mrow[k][5] = s_mag[ly + k][bc0 + 4];
-  }
-  const int4 d4 = *reinterpret_cast<const int4*>(&s_dxy[ly + 1][bc0]);
-  const int dxy4[4] = {d4.x, d4.y, d4.z, d4.w};
-  int cand[4];
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    const int ly = ps * 16 + tid / 16;
+    int mrow[3][6];  // magnitudes of rows ly, ly+1, ly+2 (mag-row coords), columns bc0-1 .. bc0+4
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int lx = lx0 + k;
-    const int m = mrow[1][k + 1];
-    int val = 0;
-    if (m > g.canny_low) {
-      const int dxy = dxy4[k];
-      const int xs = (int)(int16_t)(dxy & 0xffff), ys = dxy >> 16;
-      const int ax = abs(xs), ay = abs(ys) << 15;
-      const int tg22x = ax * TG22;
-      bool is_max;
-      if (ay < tg22x) {
-        is_max = m > mrow[1][k] && m >= mrow[1][k + 2];
-      } else {
-        const int tg67x = tg22x + (ax << 16);
-        if (ay > tg67x) {
-          is_max = m > mrow[0][k + 1] && m >= mrow[2][k + 1];
-        } else {
-          const bool neg = (xs ^ ys) < 0;  // s = -1: up-right / down-left; s = +1: up-left / down-right
-          const int mu = neg ? mrow[0][k + 2] : mrow[0][k];
-          const int md = neg ? mrow[2][k] : mrow[2][k + 2];
-          is_max = m > mu && m > md;
-        }
-      }
-      if (is_max) val = (m > g.canny_high) ? 2 : 1;
+    for (int k = 0; k < 3; ++k) {
+      const int4 m4 = *reinterpret_cast<const int4*>(&s_mag[ly + k][bc0]);
+      mrow[k][0] = s_mag[ly + k][bc0 - 1];
+      mrow[k][1] = m4.x; mrow[k][2] = m4.y; mrow[k][3] = m4.z; mrow[k][4] = m4.w;
+      mrow[k][5] = s_mag[ly + k][bc0 + 4];
     }
-    const bool inside = (x0 + lx < w) && (y0 + ly < h);
-    if (!inside) val = 0;
-    cand[k] = val;
-  }
-  // Run-based initialisation: a row of the tile is handled by 16 consecutive lanes, so its 64-bit
-  // candidate mask is an OR-butterfly over those lanes; every candidate starts with the FIRST
-  // pixel of its horizontal run as parent.  Horizontal connectivity then needs no unions at all
-  // (a 64-pixel horizontal edge used to build a 64-hop LDS chain that every later find walked),
-  // and the vertical links below produce chains bounded by the 16 rows of the tile.
-  {
-    unsigned long long rm = (unsigned long long)((cand[0] ? 1 : 0) | (cand[1] ? 2 : 0) | (cand[2] ? 4 : 0) | (cand[3] ? 8 : 0))
-                            << lx0;
+    const int4 d4 = *reinterpret_cast<const int4*>(&s_dxy[ly + 1][bc0]);
+    const int dxy4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lx = lx0 + k;
+      const int m = mrow[1][k + 1];
+      int val = 0;
+      if (m > g.canny_low) {
+        const int dxy = dxy4[k];
+        const int xs = (int)(int16_t)(dxy & 0xffff), ys = dxy >> 16;
+        const int ax = abs(xs), ay = abs(ys) << 15;
+        const int tg22x = ax * TG22;
+        bool is_max;
+        if (ay < tg22x) {
+          is_max = m > mrow[1][k] && m >= mrow[1][k + 2];
+        } else {
+          const int tg67x = tg22x + (ax << 16);
+          if (ay > tg67x) {
+            is_max = m > mrow[0][k + 1] && m >= mrow[2][k + 1];
+          } else {
+            const bool neg = (xs ^ ys) < 0;  // s = -1: up-right / down-left; s = +1: up-left / down-right
+            const int mu = neg ? mrow[0][k + 2] : mrow[0][k];
+            const int md = neg ? mrow[2][k] : mrow[2][k + 2];
+            is_max = m > mu && m > md;
+          }
+        }
+        if (is_max) val = (m > g.canny_high) ? 2 : 1;
+      }
+      const bool inside = (x0 + lx < w) && (y0 + ly < h);
+      if (!inside) val = 0;
+      cand[ps][k] = val;
+    }
+    // Run-based initialisation: a row of the tile is handled by 16 consecutive lanes, so its 64-bit
+    // candidate mask is an OR-butterfly over those lanes; every candidate starts with the FIRST
+    // pixel of its horizontal run as parent.  Horizontal connectivity then needs no unions at all
+    // and the vertical links below produce chains bounded by the rows of the tile.
+    unsigned long long rm = (unsigned long long)((cand[ps][0] ? 1 : 0) | (cand[ps][1] ? 2 : 0) | (cand[ps][2] ? 4 : 0) |
+                                                 (cand[ps][3] ? 8 : 0)) << lx0;
     rm |= __shfl_xor(rm, 1);
     rm |= __shfl_xor(rm, 2);
     rm |= __shfl_xor(rm, 4);
@@ -308,59 +309,73 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
       const int c = lx0 + k;
       const unsigned long long zeros_below = ~rm & ((1ull << c) - 1ull);
       const int start = zeros_below ? 64 - __clzll((long long)zeros_below) : 0;
-      s_lab[ly * NMS_TILE_W + c] = cand[k] ? ly * NMS_TILE_W + start : -1;
+      s_lab[ly * NMS_TILE_W + c] = cand[ps][k] ? ly * NMS_TILE_W + start : -1;
     }
   }
   __syncthreads();
   // vertical links: N if it is a candidate (then NW / NE belong to N's run), otherwise NW and NE
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (!cand[k] || ly == 0) continue;
-    const int lx = lx0 + k;
-    const int me = ly * NMS_TILE_W + lx;
-    if (s_lab[me - NMS_TILE_W] >= 0) {
-      uf_unite(s_lab, me, me - NMS_TILE_W);
-    } else {
-      if (lx > 0 && s_lab[me - NMS_TILE_W - 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W - 1);
-      if (lx < NMS_TILE_W - 1 && s_lab[me - NMS_TILE_W + 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W + 1);
-    }
-  }
-  __syncthreads();
-  // tile-local roots; a strong pixel marks its tile root (s_mag is free now: reuse row 0.. as flags)
-  int* s_strong = &s_mag[0][0];  // (NMS_TILE_H+2)*(NMS_TILE_W+3) ints >= NMS_TILE_H*NMS_TILE_W
-  int root[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    root[k] = cand[k] ? uf_find(s_lab, ly * NMS_TILE_W + lx0 + k) : -1;
-    s_strong[ly * NMS_TILE_W + lx0 + k] = 0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (cand[k] == 2) s_strong[root[k]] = 1;  // benign same-value race
-  __syncthreads();
-  if (x0 + lx0 < w && y0 + ly < h) {
-    const size_t pix = (size_t)(y0 + ly) * w + x0 + lx0;
-    uint32_t packed = 0;
-    int4 lab;
-    int* lp = &lab.x;
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    const int ly = ps * 16 + tid / 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      int key = -1;
-      uint32_t byte = (uint32_t)cand[k];  // 0 none, 1 weak, 2 strong
-      if (cand[k]) {
-        const int me = ly * NMS_TILE_W + lx0 + k;
-        const int r = root[k];
-        key = (y0 + r / NMS_TILE_W) * w + x0 + (r % NMS_TILE_W);
-        if (r == me) byte |= 8u | (s_strong[me] ? 4u : 0u);  // bit 3: tile root, bit 2: its component holds a strong pixel
+      if (!cand[ps][k] || ly == 0) continue;
+      const int lx = lx0 + k;
+      const int me = ly * NMS_TILE_W + lx;
+      if (s_lab[me - NMS_TILE_W] >= 0) {
+        uf_unite(s_lab, me, me - NMS_TILE_W);
+      } else {
+        if (lx > 0 && s_lab[me - NMS_TILE_W - 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W - 1);
+        if (lx < NMS_TILE_W - 1 && s_lab[me - NMS_TILE_W + 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W + 1);
       }
-      lp[k] = key;
-      packed |= byte << (8 * k);
     }
-    *reinterpret_cast<uint32_t*>(pl.nms[l] + (size_t)f * lv.npix + pix) = packed;
-    // parents are only ever read for candidates (every consumer tests the map first): skipping the
-    // -1 fill of the ~92 % candidate-free groups saves most of the 4 B/px label traffic
-    if (packed) *reinterpret_cast<int4*>(pl.scratch[l] + (size_t)f * lv.npix + pix) = lab;
+  }
+  __syncthreads();
+  // tile-local roots; a strong pixel marks its tile root (s_mag is free now: reused as flags)
+  int* s_strong = &s_mag[0][0];  // (NMS_TILE_H+2)*NMS_MS ints >= NMS_TILE_H*NMS_TILE_W
+  int root[NMS_PASSES][4];
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    const int ly = ps * 16 + tid / 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      root[ps][k] = cand[ps][k] ? uf_find(s_lab, ly * NMS_TILE_W + lx0 + k) : -1;
+      s_strong[ly * NMS_TILE_W + lx0 + k] = 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cand[ps][k] == 2) s_strong[root[ps][k]] = 1;  // benign same-value race
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    const int ly = ps * 16 + tid / 16;
+    if (x0 + lx0 < w && y0 + ly < h) {
+      const size_t pix = (size_t)(y0 + ly) * w + x0 + lx0;
+      uint32_t packed = 0;
+      int4 lab;
+      int* lp = &lab.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int key = -1;
+        uint32_t byte = (uint32_t)cand[ps][k];  // 0 none, 1 weak, 2 strong
+        if (cand[ps][k]) {
+          const int me = ly * NMS_TILE_W + lx0 + k;
+          const int r = root[ps][k];
+          key = (y0 + r / NMS_TILE_W) * w + x0 + (r % NMS_TILE_W);
+          if (r == me) byte |= 8u | (s_strong[me] ? 4u : 0u);  // bit 3: tile root, bit 2: its component holds a strong pixel
+        }
+        lp[k] = key;
+        packed |= byte << (8 * k);
+      }
+      *reinterpret_cast<uint32_t*>(pl.nms[l] + (size_t)f * lv.npix + pix) = packed;
+      // parents are only ever read for candidates (every consumer tests the map first): skipping the
+      // -1 fill of the ~92 % candidate-free groups saves most of the 4 B/px label traffic
+      if (packed) *reinterpret_cast<int4*>(pl.scratch[l] + (size_t)f * lv.npix + pix) = lab;
+    }
   }
 }
 
@@ -380,7 +395,7 @@ __device__ __forceinline__ bool ccl_chunk(const PyrGeom& g, int chunk, int* l_ou
 // NMS tile, one thread per BORDER pixel of the tile (top row, left column, right column): the
 // unions of a horizontal edge lying on a tile's top row run in parallel instead of 48 in a row
 // inside one thread.
-__global__ void __launch_bounds__(128) k_ccl_border(PyrGeom g, FramePlanes pl) {
+__global__ void __launch_bounds__(64 + 2 * NMS_TILE_H) k_ccl_border(PyrGeom g, FramePlanes pl) {
   const int f = g.frame0 + blockIdx.z;
   const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
   const LevelGeom& lv = g.lv[l];
@@ -390,8 +405,8 @@ __global__ void __launch_bounds__(128) k_ccl_border(PyrGeom g, FramePlanes pl) {
   const int tid = threadIdx.x;
   int lx, ly;
   if (tid < 64) { lx = tid; ly = 0; }
-  else if (tid < 80) { lx = 0; ly = tid - 64; }
-  else if (tid < 96) { lx = NMS_TILE_W - 1; ly = tid - 80; }
+  else if (tid < 64 + NMS_TILE_H) { lx = 0; ly = tid - 64; }
+  else if (tid < 64 + 2 * NMS_TILE_H) { lx = NMS_TILE_W - 1; ly = tid - 64 - NMS_TILE_H; }
   else return;
   if (tid >= 64 && ly == 0) return;  // the corners belong to the top row
   const int x = x0 + lx, y = y0 + ly;
@@ -782,7 +797,7 @@ void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 
 void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid((g.lv[0].npix / 16 + 255) / 256, g.n_levels, B);
-  hipLaunchKernelGGL(k_ccl_border, dim3(g.total_tiles, 1, B), dim3(128), 0, s, g, p);
+  hipLaunchKernelGGL(k_ccl_border, dim3(g.total_tiles, 1, B), dim3(64 + 2 * NMS_TILE_H), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_out, dim3((g.lv[0].npix / 4 + 255) / 256, g.n_levels, B), dim3(256), 0, s, g, p);
 }
