@@ -95,8 +95,15 @@ struct EvalOut {
 
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
 #define NMS_TILE_W 64
-#define NMS_TILE_H 16              // multiple of 16 (64x32 measured slower: 223 vs 176 us, LDS-limited occupancy)
-#define NMS_PASSES (NMS_TILE_H / 16)
+#ifndef NMS_TILE_H
+#define NMS_TILE_H 16
+#endif
+// NMS_TILE_H: multiple of 16 (64x32 measured slower: 223 vs 176 us, LDS-limited occupancy)
+#ifndef NMS_THREADS
+#define NMS_THREADS 256             // 16 threads (x 4 px) per tile row
+#endif
+#define NMS_ROWS_PER_PASS (NMS_THREADS / 16)
+#define NMS_PASSES (NMS_TILE_H / NMS_ROWS_PER_PASS)
 #define TRACK_THREADS 512
 #define TRACK_MAX_CLUSTER 8
 

@@ -184,7 +184,7 @@ __device__ __forceinline__ void uf_unite(P* L, int a, int b) {
 //   s_dxy [18][76] ints  : dx | dy << 16
 #define NMS_GW 19
 #define NMS_MS 76
-__global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
+__global__ void __launch_bounds__(NMS_THREADS) k_canny_nms(PyrGeom g, FramePlanes pl) {
   __shared__ uint32_t s_gw[NMS_TILE_H + 4][NMS_GW];
   __shared__ __attribute__((aligned(16))) int s_mag[NMS_TILE_H + 2][NMS_MS];
   __shared__ __attribute__((aligned(16))) int s_dxy[NMS_TILE_H + 2][NMS_MS];
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
 
   // phase A: gray tile as aligned words (w is a multiple of 4, x0 of 64: a word is entirely inside
   // or entirely outside the image; outside = BORDER_REPLICATE of the edge pixel)
-  for (int i = tid; i < (NMS_TILE_H + 4) * 18; i += 256) {
+  for (int i = tid; i < (NMS_TILE_H + 4) * 18; i += NMS_THREADS) {
     const int r = i / 18, wc = i - r * 18;
     const int gy = clampi(y0 - 2 + r, 0, h - 1);
     const int gx = x0 - 4 + 4 * wc;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   }
   __syncthreads();
   // phase B: Sobel 3x3 + L2 magnitude, 4 adjacent positions per task from 9 word reads
-  for (int i = tid; i < (NMS_TILE_H + 2) * 18; i += 256) {
+  for (int i = tid; i < (NMS_TILE_H + 2) * 18; i += NMS_THREADS) {
     const int r = i / 18, c = i - r * 18;
     const int iy = y0 - 1 + r;
     // bytes bc = 4c-1 .. 4c+4 of gray rows r, r+1, r+2
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   int cand[NMS_PASSES][4];
 #pragma unroll
   for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * 16 + tid / 16;
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
     int mrow[3][6];  // magnitudes of rows ly, ly+1, ly+2 (mag-row coords), columns bc0-1 .. bc0+4
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   // vertical links: N if it is a candidate (then NW / NE belong to N's run), otherwise NW and NE
 #pragma unroll
   for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * 16 + tid / 16;
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (!cand[ps][k] || ly == 0) continue;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   int root[NMS_PASSES][4];
 #pragma unroll
   for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * 16 + tid / 16;
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       root[ps][k] = cand[ps][k] ? uf_find(s_lab, ly * NMS_TILE_W + lx0 + k) : -1;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * 16 + tid / 16;
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
     if (x0 + lx0 < w && y0 + ly < h) {
       const size_t pix = (size_t)(y0 + ly) * w + x0 + lx0;
       uint32_t packed = 0;
@@ -792,7 +792,7 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
 }
 
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_canny_nms, dim3(g.total_tiles, 1, B), dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_canny_nms, dim3(g.total_tiles, 1, B), dim3(NMS_THREADS), 0, s, g, p);
 }
 
 void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
