@@ -223,6 +223,38 @@ class TrackerNew {  // tracker.h:56-105
   Optimizer mOptimizer;
 };
 
+// ---- REVO: the sequencing of REVO::start (system.cpp:84-305) ------------------------
+// submit() is the producer side (IOWrapperRGBD::generateImgPyramid: build + queue, asynchronous on
+// the device), trackNext() one body of the consumer loop; poses are curr->world, column-major 4x4.
+class REVO {
+ public:
+  explicit REVO(const std::shared_ptr<CameraPyr>& cam) : cam_(cam) { check(revo_vo_create(cam->ctx(), &vo_), "REVO"); }
+  ~REVO() { revo_vo_destroy(vo_); }
+  REVO(const REVO&) = delete;
+  REVO& operator=(const REVO&) = delete;
+  void submit(const uint8_t* bgr, size_t bgr_stride, const float* depth_m, size_t depth_stride, double ts) {
+    check(revo_vo_submit(vo_, bgr, bgr_stride, depth_m, depth_stride, ts), "REVO::submit");
+  }
+  template <class MatRGB, class MatDepth>
+  void submit(const MatRGB& rgb, const MatDepth& depth, double ts) {
+    submit((const uint8_t*)rgb.data, (size_t)rgb.step, (const float*)depth.data, (size_t)depth.step, ts);
+  }
+  // returns false when the queue is empty
+  template <class M4>
+  bool trackNext(M4& pose, bool* newKeyframe = nullptr, double* timestamp = nullptr) {
+    if (revo_vo_queued(vo_) == 0) return false;
+    int kf = 0;
+    check(revo_vo_track_next(vo_, pose.data(), &kf, timestamp), "REVO::trackNext");
+    if (newKeyframe) *newKeyframe = kf != 0;
+    return true;
+  }
+  int numKeyframes() const { return revo_vo_num_keyframes(vo_); }
+
+ private:
+  std::shared_ptr<CameraPyr> cam_;
+  revo_vo* vo_ = nullptr;
+};
+
 // ---- tiny column-major helpers for hosts without Eigen ---------------------------
 struct Mat3f { float m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; float* data() { return m; } const float* data() const { return m; } };
 struct Vec3f { float v[3] = {0, 0, 0}; float* data() { return v; } const float* data() const { return v; } };
