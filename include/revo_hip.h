@@ -277,6 +277,10 @@ int revo_vo_create(revo_ctx* ctx, revo_vo** out);
 void revo_vo_destroy(revo_vo* vo);
 int revo_vo_submit(revo_vo* vo, const uint8_t* bgr, size_t bgr_stride,
                    const float* depth_m, size_t depth_stride, double timestamp);
+/* Same with raw uint16 depth (iowrapperRGBD.cpp:326-327 fused into the device build). */
+int revo_vo_submit_u16(revo_vo* vo, const uint8_t* bgr, size_t bgr_stride,
+                       const uint16_t* depth_raw, size_t depth_stride,
+                       double depth_scale_factor, double timestamp);
 /* pose_colmajor: 4x4 curr->world as REVO::writePose would emit it (system.cpp:275);
  * *new_keyframe: 1 if this frame created a keyframe.  REVO_ERR_INVALID_ARG if the queue is empty. */
 int revo_vo_track_next(revo_vo* vo, float pose_colmajor[16], int* new_keyframe,

@@ -96,6 +96,7 @@ def lib():
     L.revo_vo_destroy.argtypes = [vp]
     L.revo_vo_destroy.restype = None
     L.revo_vo_submit.argtypes = [vp, u8p, C.c_size_t, f32p, C.c_size_t, C.c_double]
+    L.revo_vo_submit_u16.argtypes = [vp, u8p, C.c_size_t, u16p, C.c_size_t, C.c_double, C.c_double]
     L.revo_vo_track_next.argtypes = [vp, f32p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.revo_vo_queued.argtypes = [vp]
     L.revo_vo_num_keyframes.argtypes = [vp]

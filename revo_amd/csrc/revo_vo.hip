@@ -102,6 +102,16 @@ extern "C" int revo_vo_submit(revo_vo* v, const uint8_t* bgr, size_t bgr_stride,
   return REVO_OK;
 }
 
+extern "C" int revo_vo_submit_u16(revo_vo* v, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth_raw,
+                                  size_t depth_stride, double depth_scale_factor, double ts) {
+  if (!v) return REVO_ERR_INVALID_ARG;
+  Frame f{nullptr, ts, M4::identity()};
+  const int rc = revo_pyramid_create_u16(v->ctx, bgr, bgr_stride, depth_raw, depth_stride, depth_scale_factor, ts, &f.pyr);
+  if (rc) return rc;
+  v->queue.push_back(f);
+  return REVO_OK;
+}
+
 // one body of the while loop of REVO::start (system.cpp:128-284)
 extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_out, double* ts_out) {
   if (!v || v->queue.empty()) return REVO_ERR_INVALID_ARG;

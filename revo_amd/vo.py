@@ -14,12 +14,12 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, api
-from ._lib import check, f32p, u8p, vp
+from ._lib import check, f32p, u16p, u8p, vp
 from .settings import TrackerSettings
 
 
 class REVO:
-    def __init__(self, settingsPyr, settingsTracker=None, device=0, cameraPyr=None):
+    def __init__(self, settingsPyr, settingsTracker=None, device=0, cameraPyr=None, depth_scale_factor=None):
         self.settingsPyr = settingsPyr
         self.settingsTracker = settingsTracker or TrackerSettings()
         self.camPyr = cameraPyr or api.CameraPyr(settingsPyr, device=device)
@@ -27,6 +27,7 @@ class REVO:
         self._h = vp()
         check(_lib.lib().revo_vo_create(self.camPyr._h, C.byref(self._h)))
         self.poses = []  # (timestamp, 4x4 curr->world)
+        self.depth_scale_factor = depth_scale_factor  # set: depth arrives as raw uint16
 
     def __del__(self):
         try:
@@ -43,6 +44,15 @@ class REVO:
     def submit(self, bgr, depth, timestamp):
         """IOWrapperRGBD::generateImgPyramidFromFiles: build the pyramid, push it to the queue."""
         bgr = np.ascontiguousarray(bgr, np.uint8)
+        if self.depth_scale_factor is not None and np.asarray(depth).dtype == np.uint16:
+            # iowrapperRGBD.cpp:326-327 (depth.convertTo(CV_32FC1, 1/scale)) runs inside the device build
+            raw = np.ascontiguousarray(depth, np.uint16)
+            h, w = raw.shape
+            if bgr.shape != (h, w, 3) or (w, h) != (self.settingsPyr.width, self.settingsPyr.height):
+                raise ValueError("image size does not match the settings")
+            check(_lib.lib().revo_vo_submit_u16(self._h, bgr.ctypes.data_as(u8p), w * 3, raw.ctypes.data_as(u16p), w * 2,
+                                                float(self.depth_scale_factor), float(timestamp)))
+            return
         depth = np.ascontiguousarray(depth, np.float32)
         h, w = depth.shape
         if bgr.shape != (h, w, 3) or (w, h) != (self.settingsPyr.width, self.settingsPyr.height):

@@ -1,0 +1,74 @@
+"""Dataset front-end and configuration readers: TUM associate/PNG layout
+and the reference's OpenCV-FileStorage YAML keys, without OpenCV."""
+import numpy as np
+
+from revo_amd import config, synth, tum
+from revo_amd.settings import ImgPyramidSettings
+
+DATASET_YAML = """%YAML:1.0
+# Camera Parameters
+Camera.fx: 517.306408
+Camera.fy: 516.469215
+Camera.cx: 318.643040
+Camera.cy: 255.313989
+Camera.width: 640
+Camera.height: 480
+cannyThreshold1: 150
+cannyThreshold2: 100
+MainFolder: "/data/tum/"
+Datasets: "rgbd_dataset_freiburg1_xyz"
+ASSOCIATE: "associate.txt"
+PYR_MIN_LVL: 2
+PYR_MAX_LVL: 0
+DEPTH_MIN: 0.1 #in [m]
+DEPTH_MAX: 5.2
+USE_EDGE_HIST: 1
+nPercentage: 0.3
+useDepthTimeStamp: 0
+SKIP_FIRST_N_FRAMES: 0
+READ_N_IMAGES: 1000
+DEPTH_SCALE_FACTOR: 5000.0
+"""
+SETTINGS_YAML = """%YAML:1.0
+DO_GENERATE_DENSE_PCL: 0
+CHECK_TRACKING_RESULTS: 1
+CHECK_INIT_VALUES: 0
+USE_EDGE_FILTER: 1
+N_FRAMES_HIST_VOTING: 3
+DO_OUTPUT_POSES: 1
+"""
+
+
+def test_yaml_readers(tmp_path):
+    d, st = tmp_path / "dataset.yaml", tmp_path / "settings.yaml"
+    d.write_text(DATASET_YAML)
+    st.write_text(SETTINGS_YAML)
+    s, io = config.load_dataset_yaml(str(d))
+    ref = ImgPyramidSettings()
+    assert bytes(s) == bytes(ref)  # the TUM-1 values are the library defaults
+    assert io["datasets"] == ["rgbd_dataset_freiburg1_xyz"] and io["depth_scale_factor"] == 5000.0
+    assert io["read_n_images"] == 1000 and io["main_folder"] == "/data/tum/"
+    ts, filt, sysd = config.load_settings_yaml(str(st))
+    assert ts.check_init_values == 0 and ts.check_tracking_results == 1 and ts.n_frames_hist_voting == 3
+    assert filt == 1 and sysd["do_output_poses"] == 1
+    # defaults for missing keys follow cv::read(..., default) (camerapyr.h:40-64)
+    e = tmp_path / "empty.yaml"
+    e.write_text("%YAML:1.0\nCamera.width: 320\nCamera.height: 240\n")
+    s2, _ = config.load_dataset_yaml(str(e))
+    assert s2.fx == (320 + 240) / 2 and s2.fy == s2.fx and s2.cx == 160 and s2.pyr_min_lvl == 2
+
+
+def test_tum_layout_roundtrip(tmp_path):
+    s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
+    seq = synth.make_sequence(1, s, 4)
+    folder = str(tmp_path / "rgbd_dataset_synth")
+    tum.write_synthetic_dataset(folder, seq)
+    rows = tum.read_associate(folder + "/associate.txt")
+    assert len(rows) == 4 and rows[0][1].startswith("rgb/") and rows[0][3].startswith("depth/")
+    assert len(tum.read_associate(folder + "/associate.txt", skip_first_n_frames=1, read_n_images=2)) == 2
+    got = list(tum.frames(folder))
+    for (bgr, raw, ts), (bgr0, depth0, ts0, T) in zip(got, seq):
+        assert np.array_equal(bgr, bgr0) and abs(ts - ts0) < 1e-6 and raw.dtype == np.uint16
+        assert np.abs(raw.astype(np.float32) / 5000.0 - depth0).max() <= 0.5 / 5000.0 + 1e-6
+    gt = tum.read_groundtruth_positions(folder + "/groundtruth.txt")
+    assert len(gt) == 4

@@ -45,3 +45,47 @@ def test_vo_matches_oracle_trajectory_and_keyframes():
     assert len(lines) == len(frames) and len(lines[3].split()) == 8
     q = np.array(lines[3].split()[4:], np.float64)
     assert abs(np.linalg.norm(q) - 1) < 1e-5
+
+
+def test_run_tum_cli_on_a_synthetic_tum_dataset(tmp_path, monkeypatch):
+    """main.cpp's `REVO <settings.yaml> <dataset.yaml>` for a TUM-layout folder (PNG decode via PIL, u16
+    depth converted on the device) vs the oracle's REVO::start on the same decoded frames."""
+    from oracle import ro
+    from revo_amd import run_tum, synth, tum
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(320, 240, 3)
+    seq = synth.make_sequence(9, s, 16, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
+    folder = tmp_path / "data" / "rgbd_dataset_synth"
+    tum.write_synthetic_dataset(str(folder), seq)
+    (tmp_path / "dataset.yaml").write_text(
+        "%%YAML:1.0\nCamera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.width: 320\nCamera.height: 240\n"
+        "MainFolder: \"%s/\"\nDatasets: \"rgbd_dataset_synth\"\nASSOCIATE: \"associate.txt\"\n"
+        "PYR_MIN_LVL: 2\nPYR_MAX_LVL: 0\nDEPTH_SCALE_FACTOR: 5000.0\n"
+        % (float(s.fx), float(s.fy), float(s.cx), float(s.cy), str(tmp_path / "data")))
+    (tmp_path / "settings.yaml").write_text("%YAML:1.0\nCHECK_TRACKING_RESULTS: 1\nCHECK_INIT_VALUES: 1\nUSE_EDGE_FILTER: 1\n"
+                                            "N_FRAMES_HIST_VOTING: 3\nDO_OUTPUT_POSES: 1\n")
+    monkeypatch.chdir(tmp_path)
+    assert run_tum.main([str(tmp_path / "settings.yaml"), str(tmp_path / "dataset.yaml")]) == 0
+    lines = (tmp_path / "poses_rgbd_dataset_synth.txt").read_text().strip().splitlines()
+    assert len(lines) == 16
+    est = []
+    for ln in lines:
+        v = [float(x) for x in ln.split()]
+        M = np.eye(4)
+        M[:3, 3] = v[1:4]
+        est.append(M)
+    from revo_amd import config
+    s_cfg, _ = config.load_dataset_yaml(str(tmp_path / "dataset.yaml"))
+    cpu = ro.VO(s_cfg)
+    ref = []
+    for bgr, raw, ts in tum.frames(str(folder)):
+        ref.append(cpu.push(bgr, ro.u16_to_depth(raw, 5000.0), ts)[0])
+    # Two faithful implementations of the same LM may stop at different points inside its 0.999
+    # convergence slack (1e-8 differences in the init flip borderline accept/stop decisions; measured
+    # up to 3 mm per frame at this resolution, with identical keyframe decisions).  The bar is the
+    # ATE DIFFERENCE vs ground truth (SURVEY 8a / north star: within 1 mm of the reference's ATE).
+    gt = [f[3] for f in seq]
+    ate_g, ate_o = synth.ate_rmse(est, gt), synth.ate_rmse(ref, gt)
+    print("ATE vs GT: HIP %.4f m, oracle %.4f m; trajectory vs trajectory %.4f m" % (ate_g, ate_o, synth.ate_rmse(est, ref)))
+    assert abs(ate_g - ate_o) < 1e-3 and ate_g < 0.01
+    assert synth.ate_rmse(est, ref) < 5e-3
