@@ -2,5 +2,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -q -m gpu -s > gpurun_out/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest.log
-grep -E "passed|failed|Error|error|ATE" gpurun_out/pytest.log | head -20
+timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest.log
+grep -E "passed|failed|Error|error|assert" gpurun_out/pytest.log | head -20

@@ -368,3 +368,70 @@ def test_1280x960_five_levels(api, ro):
     assert dr < ROT_TOL and dt < TRANS_TOL and st_g == r_o["status"]
     er, et = synth.pose_error(R_g, T_g, pair["T_ref_curr"])
     assert er < 2e-3 and et < 3e-3
+
+
+def test_pool_reuse_and_async_build_stress(api, ro):
+    """Pyramids are built asynchronously on a second stream into pooled, recycled device sets.  Interleave
+    create / track / destroy so sets are reused while earlier work is still in flight: every result must
+    equal a fresh computation, bit for bit."""
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    pairs = [synth.make_pair(200 + i, s) for i in range(3)]
+    cam = api.CameraPyr(s)
+    trk = api.TrackerNew(TrackerSettings(), s, cam)
+    ref_results = []
+    for p in pairs:  # fresh, sequential
+        a = api.ImgPyramidRGBD(s, cam, *p["ref"])
+        b = api.ImgPyramidRGBD(s, cam, *p["curr"])
+        a.makeKeyframe()
+        ref_results.append((trk.trackFrames(np.eye(3), np.zeros(3), a, b), b.return3DEdges(0), a.returnDistTransform(1)))
+        del a, b
+    rng = np.random.default_rng(0)
+    live = []
+    for it in range(40):
+        k = int(rng.integers(0, 3))
+        p = pairs[k]
+        a = api.ImgPyramidRGBD(s, cam, *p["ref"])   # these two builds are queued back to back,
+        b = api.ImgPyramidRGBD(s, cam, *p["curr"])  # the tracker below waits on their events
+        a.makeKeyframe()
+        got = trk.trackFrames(np.eye(3), np.zeros(3), a, b)
+        exp = ref_results[k][0]
+        assert got[0] == exp[0] and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]) and got[3] == exp[3], it
+        if it % 7 == 0:
+            assert np.array_equal(b.return3DEdges(0), ref_results[k][1])
+            assert np.array_equal(a.returnDistTransform(1), ref_results[k][2])
+        live.append((a, b))
+        if len(live) > 3:  # destroy out of order -> recycled sets
+            live.pop(int(rng.integers(0, len(live))))
+
+
+@pytest.mark.parametrize("n_pairs", [1, 3, 9])
+def test_batch_sizes_not_multiple_of_eight(api, n_pairs):
+    """The tracker grid is padded to groups of 8 pairs (XCD-affine mapping): other sizes must still work."""
+    import torch
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    pairs = [synth.make_pair(300 + (i % 3), s) for i in range(n_pairs)]
+    cam = api.CameraPyr(s)
+    trk = api.TrackerNew(TrackerSettings(), s, cam)
+    bgr = np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])
+    dep = np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])
+    d_bgr, d_dep = torch.from_numpy(bgr).cuda(), torch.from_numpy(dep).cuda()
+    d_res = torch.zeros(n_pairs * 96, dtype=torch.uint8, device="cuda")
+    bt = api.BatchTracker(cam, n_pairs)
+    init = api.pack_init_RT([np.eye(3)] * n_pairs, [np.zeros(3)] * n_pairs)
+    for _ in range(2):  # twice: the mailbox / descriptors are re-initialised per launch
+        bt.track(d_bgr.data_ptr(), d_dep.data_ptr(), d_res.data_ptr(), init_RT=init)
+        bt.sync()
+    res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), n_pairs)
+    single = {}
+    for i, p in enumerate(pairs):
+        key = 300 + (i % 3)
+        if key not in single:
+            a = api.ImgPyramidRGBD(s, cam, *p["ref"])
+            b = api.ImgPyramidRGBD(s, cam, *p["curr"])
+            a.makeKeyframe()
+            single[key] = trk.trackFrames(np.eye(3), np.zeros(3), a, b)
+        st, R, T, err = single[key]
+        # the cluster size differs between the 1-pair and the n-pair launch: same algorithm, sums grouped
+        # differently -> equal within the SE(3) tolerance, not bitwise
+        assert synth.rot_angle(res[i]["R"], R) < ROT_TOL and np.linalg.norm(res[i]["T"] - T) < TRANS_TOL
+        assert res[i]["flags"] == 0
