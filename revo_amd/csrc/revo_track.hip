@@ -410,8 +410,9 @@ __device__ __forceinline__ void eval_level(const f4v* preg, gf4p pts, int first,
                                            float wlim, float hlim, float ed, bool filt, float huber, float* acc) {
 #pragma unroll
   for (int k = 0; k < TRACK_MAXP; ++k) {
+    // (measured alternatives: two predicated points in flight 0.544 ms vs 0.505 ms for this form;
+    //  skipping the cluster exchange on small levels by evaluating them redundantly: 0.501 ms, not kept)
     if (first + k * stride < N) eval_one(preg[k], dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
-    __builtin_amdgcn_sched_barrier(0);  // keep the unrolled points sequential: 4 waves/SIMD hide the latency, not ILP
   }
   for (int i = first + TRACK_MAXP * stride; i < N; i += stride)
     eval_one(pts[i], dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
