@@ -177,6 +177,13 @@ typedef enum revo_plane {
 int revo_pyramid_read(revo_pyr* pyr, revo_plane what, int lvl, void* host_dst,
                       size_t cap_bytes, size_t* count);
 
+/* ImgPyramidRGBD::generateColoredPcl(lvl, clrPcl, densePcl) (imgpyramidrgbd.cpp:279-327), the
+ * cloud REVO::start hands to the viewer / PLY export per keyframe (system.cpp:165,235):
+ * 8 floats per point (X,Y,Z,1, r,g,b,1 with colours in [0,1]), x-outer / y-inner order;
+ * dense != 0: every pixel with a usable depth, else edge pixels only.  dst8 == NULL only
+ * counts.  Single-frame pyramids only (batch views keep no colour image). */
+int revo_pyramid_colored_pcl(revo_pyr* p, int lvl, int dense, float* dst8, size_t cap_points, size_t* count);
+
 /* ---- Optimizer ------------------------------------------------------------ */
 
 /* float Optimizer::trackFrames(ref, curr, R, T, lvl, resInfo),
@@ -287,6 +294,10 @@ int revo_vo_track_next(revo_vo* vo, float pose_colmajor[16], int* new_keyframe,
                        double* timestamp);
 int revo_vo_queued(const revo_vo* vo);
 int revo_vo_num_keyframes(const revo_vo* vo);
+/* The current keyframe (kfPyr) and its pose in the world (getTransKFtoWorld), as REVO::start hands
+ * them to the map drawer after a keyframe change (system.cpp:165-167,235-237).  The handle is
+ * borrowed: valid until the next revo_vo_track_next / revo_vo_destroy. */
+int revo_vo_keyframe(const revo_vo* v, revo_pyr** kf_out, float T_w_kf[16]);
 
 #ifdef __cplusplus
 }

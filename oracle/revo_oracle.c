@@ -566,6 +566,7 @@ static void mat4_to_RT(const float M[16], float R[9], float T[3]) {
 typedef struct { float fx, fy, cx, cy; int width, height; } ro_camera;
 
 struct ro_pyramid {
+  uint8_t* bgr_full;  /* rgbFullSize = fullResRgb.clone(), imgpyramidrgbd.cpp:51 */
   revo_pyr_settings s;
   int n_levels;
   double ts;
@@ -636,6 +637,8 @@ ro_pyramid* ro_pyramid_create(const revo_pyr_settings* s, const uint8_t* bgr,
   make_cameras(s, p->n_levels, p->cam);
   mat4_identity(p->T_w_f);
   const int w = s->width, h = s->height;
+  p->bgr_full = (uint8_t*)malloc((size_t)w * h * 3);
+  for (int y = 0; y < h; ++y) memcpy(p->bgr_full + (size_t)y * w * 3, bgr + (size_t)y * bgr_stride, (size_t)w * 3);
   uint8_t* gray = (uint8_t*)malloc((size_t)w * h);
   ro_bgr2gray(bgr, bgr_stride, w, h, gray);
   float* depth = (float*)malloc(sizeof(float) * (size_t)w * h);
@@ -655,6 +658,7 @@ ro_pyramid* ro_pyramid_create(const revo_pyr_settings* s, const uint8_t* bgr,
 
 void ro_pyramid_destroy(ro_pyramid* p) {
   if (!p) return;
+  free(p->bgr_full);
   for (int l = 0; l < REVO_MAX_LEVELS; ++l) {
     free(p->gray[l]); free(p->depth[l]); free(p->edges[l]); free(p->edges_orig[l]);
     free(p->hist[l]); free(p->pts[l]); free(p->dt[l]); free(p->table[l]);
@@ -700,6 +704,60 @@ size_t ro_pyramid_read(const ro_pyramid* p, int what, int lvl, void* dst, size_t
   }
   if (dst && src && count * esz <= cap) memcpy(dst, src, count * esz);
   return count;
+}
+
+/* cv::pyrDown on a 3-channel BGR8 image (imgpyramidrgbd.cpp:290-295): the same 5x5 kernel per channel. */
+static void pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst) {
+  const int dw = w / 2, dh = h / 2;
+  static const int k[5] = {1, 4, 6, 4, 1};
+  for (int y = 0; y < dh; ++y)
+    for (int x = 0; x < dw; ++x)
+      for (int c = 0; c < 3; ++c) {
+        int sum = 0;
+        for (int j = -2; j <= 2; ++j) {
+          const int sy = reflect101(2 * y + j, h);
+          int rowsum = 0;
+          for (int i = -2; i <= 2; ++i) rowsum += k[i + 2] * src[((size_t)sy * w + reflect101(2 * x + i, w)) * 3 + c];
+          sum += k[j + 2] * rowsum;
+        }
+        dst[((size_t)y * dw + x) * 3 + c] = (uint8_t)((sum + 128) >> 8);
+      }
+}
+
+/* ImgPyramidRGBD::generateColoredPcl(lvl, clrPcl, densePcl), imgpyramidrgbd.cpp:279-327:
+ * out8 receives (X,Y,Z,1,r,g,b,1) per point, x outer / y inner; returns the point count.
+ * (The reference handles lvl 0..2 explicitly; here the colour image is pyrDown'ed lvl times.) */
+size_t ro_pyramid_colored_pcl(const ro_pyramid* p, int lvl, int dense, float* out8, size_t cap_points) {
+  if (lvl < 0 || lvl >= p->n_levels) return 0;
+  int w = p->cam[0].width, h = p->cam[0].height;
+  uint8_t* rgb = (uint8_t*)malloc((size_t)w * h * 3);
+  memcpy(rgb, p->bgr_full, (size_t)w * h * 3);
+  for (int l = 0; l < lvl; ++l) {
+    uint8_t* d = (uint8_t*)malloc((size_t)(w / 2) * (h / 2) * 3);
+    pyrdown_bgr(rgb, w, h, d);
+    free(rgb); rgb = d; w /= 2; h /= 2;
+  }
+  const ro_camera cam = p->cam[lvl];
+  const uint8_t* edges = p->edges[lvl];
+  const float* depth = p->depth[lvl];
+  size_t n = 0;
+  for (int xx = 0; xx < w; ++xx)
+    for (int yy = 0; yy < h; ++yy) {
+      const float Z = depth[(size_t)yy * w + xx];
+      if (isfinite(Z) && Z > p->s.depth_min && Z < p->s.depth_max) {
+        if (dense || edges[(size_t)yy * w + xx] > 0) {
+          if (out8 && n < cap_points) {
+            const uint8_t* clr = rgb + ((size_t)yy * w + xx) * 3;
+            float* v = out8 + 8 * n;
+            v[0] = Z * (xx - cam.cx) / cam.fx; v[1] = Z * (yy - cam.cy) / cam.fy; v[2] = Z; v[3] = 1.0f;
+            v[4] = clr[2] / 255.0f; v[5] = clr[1] / 255.0f; v[6] = clr[0] / 255.0f; v[7] = 1.0f;
+          }
+          ++n;
+        }
+      }
+    }
+  free(rgb);
+  return n;
 }
 
 /* ======================================================================== */

@@ -81,6 +81,8 @@ int ro_pyramid_is_keyframe(const ro_pyramid* p);
 size_t ro_pyramid_read(const ro_pyramid* p, int what, int lvl, void* dst,
                        size_t cap_bytes);
 void ro_pyramid_camera(const ro_pyramid* p, int lvl, float out6[6]);
+/* generateColoredPcl (imgpyramidrgbd.cpp:279-327): 8 floats per point; returns the count */
+size_t ro_pyramid_colored_pcl(const ro_pyramid* p, int lvl, int dense, float* out8, size_t cap_points);
 
 /* ---- Optimizer / TrackerNew ---------------------------------------------- */
 typedef struct ro_tracker ro_tracker;

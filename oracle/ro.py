@@ -53,6 +53,8 @@ def lib():
         L.ro_pyramid_read.restype = C.c_size_t
         L.ro_pyramid_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.ro_pyramid_camera.argtypes = [C.c_void_p, C.c_int, f32p]
+        L.ro_pyramid_colored_pcl.restype = C.c_size_t
+        L.ro_pyramid_colored_pcl.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_size_t]
         L.ro_tracker_create.restype = C.c_void_p
         L.ro_tracker_create.argtypes = [C.POINTER(ImgPyramidSettings), C.POINTER(OptimizerSettings),
                                         C.POINTER(TrackerSettings)]
@@ -282,6 +284,12 @@ class Pyramid:
     def camera(self, lvl):
         out = np.empty(6, np.float32)
         lib().ro_pyramid_camera(self.h, lvl, _p(out, f32p))
+        return out
+
+    def generateColoredPcl(self, lvl, dense):
+        n = lib().ro_pyramid_colored_pcl(self.h, lvl, int(dense), None, 0)
+        out = np.empty((n, 8), np.float32)
+        lib().ro_pyramid_colored_pcl(self.h, lvl, int(dense), _p(out, f32p), n)
         return out
 
 

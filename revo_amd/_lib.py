@@ -74,6 +74,7 @@ def lib():
     L.revo_pyramid_timestamp.argtypes = [vp]
     L.revo_pyramid_timestamp.restype = C.c_double
     L.revo_pyramid_read.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.revo_pyramid_colored_pcl.argtypes = [vp, C.c_int, C.c_int, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.revo_optimizer_track_level.argtypes = [vp, vp, vp, f32p, f32p, C.c_int, C.POINTER(ResidualInfo), f32p]
     L.revo_optimizer_eval.argtypes = [vp, vp, vp, f32p, f32p, C.c_int, C.POINTER(ResidualInfo), f32p, f32p, f32p]
     L.revo_tracker_track_frames.argtypes = [vp, vp, vp, f32p, f32p, f32p, C.POINTER(C.c_int),
@@ -99,6 +100,7 @@ def lib():
     L.revo_vo_submit_u16.argtypes = [vp, u8p, C.c_size_t, u16p, C.c_size_t, C.c_double, C.c_double]
     L.revo_vo_track_next.argtypes = [vp, f32p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.revo_vo_queued.argtypes = [vp]
+    L.revo_vo_keyframe.argtypes = [vp, vpp, f32p]
     L.revo_vo_num_keyframes.argtypes = [vp]
     _lib = L
     return L

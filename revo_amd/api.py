@@ -161,6 +161,16 @@ class ImgPyramidRGBD:
         """N x 4 float32 rows (X,Y,Z,1) == the columns of the reference's 4xN Eigen::MatrixXf."""
         return self._read(PLANE_EDGES3D, lvl)
 
+    def generateColoredPcl(self, lvl, densePcl=False):
+        """imgpyramidrgbd.cpp:279-327: N x 8 float32 rows (X,Y,Z,1,r,g,b,1), colours in [0,1] ==
+        the columns of the reference's 8xN clrPcl; densePcl: every usable-depth pixel, else edges."""
+        w, h = self.mSettings.level_size(lvl)
+        buf = np.empty((w * h, 8), np.float32)
+        n = C.c_size_t()
+        check(_lib.lib().revo_pyramid_colored_pcl(self._h, lvl, int(bool(densePcl)), buf.ctypes.data_as(_lib.f32p),
+                                                  w * h, C.byref(n)))
+        return buf[:n.value].copy()
+
     def returnDepth(self, lvl):
         return self._read(PLANE_DEPTH, lvl)
 

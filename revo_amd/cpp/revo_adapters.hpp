@@ -17,6 +17,7 @@
 // (Sophus ENSURE, common.hpp:117-136).  Define REVO_ADAPTERS_THROW to get
 // std::runtime_error instead.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -109,6 +110,20 @@ class ImgPyramidRGBD {  // imgpyramidrgbd.h:27-250
 
   // accessors: lazy device->host copies (imgpyramidrgbd.h:45-117)
   std::vector<float> return3DEdges(unsigned lvl) const { return readF(REVO_PLANE_EDGES3D, lvl, 4); }  // 4 x N col-major
+  // imgpyramidrgbd.cpp:279-327: 8 x N column-major (X,Y,Z,1,r,g,b,1)
+  std::vector<float> generateColoredPcl(unsigned lvl, bool densePcl) const {
+    size_t n = 0;
+    check(revo_pyramid_colored_pcl(pyr_, (int)lvl, densePcl ? 1 : 0, nullptr, 0, &n), "generateColoredPcl");
+    std::vector<float> v(n * 8);
+    if (n) check(revo_pyramid_colored_pcl(pyr_, (int)lvl, densePcl ? 1 : 0, v.data(), n, &n), "generateColoredPcl");
+    return v;
+  }
+  template <class MatX>
+  void generateColoredPcl(unsigned lvl, MatX& clrPcl, bool densePcl) const {  // the reference's signature (Eigen::MatrixXf)
+    const std::vector<float> v = generateColoredPcl(lvl, densePcl);
+    clrPcl.resize(8, (long)(v.size() / 8));
+    std::copy(v.begin(), v.end(), clrPcl.data());
+  }
   std::vector<float> returnOptimizationStructure(unsigned lvl) const { return readF(REVO_PLANE_GRADTABLE, lvl, 4); }
   std::vector<float> returnDistTransform(unsigned lvl) const { return readF(REVO_PLANE_DT, lvl, 1); }
   std::vector<float> returnDepth(unsigned lvl) const { return readF(REVO_PLANE_DEPTH, lvl, 1); }

@@ -116,6 +116,9 @@ void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 // keyframe promotion of frames f0, f0+fstride, ... (count frames)
+void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
+void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int lvl, int dense, const uint8_t* bgr_lvl,
+                        int* chunk, unsigned* cmask, int* total, int cap, float* out8, hipStream_t s);
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
                   int n_pairs, unsigned long long* d_mail, int cluster, hipStream_t s);

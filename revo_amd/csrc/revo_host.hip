@@ -101,6 +101,8 @@ struct revo_ctx {
   // vote
   std::deque<Past> past;
   int* d_marks; int* d_hist8; int* h_hist8;
+  // coloured point cloud (generateColoredPcl), allocated on first use
+  char* d_pcl = nullptr; float* d_pcl_out; uint8_t* d_pcl_clr[2]; int* d_pcl_chunk; unsigned* d_pcl_mask; int* d_pcl_total;
   const float4** d_cloud_pts; const int** d_cloud_n; float* d_RT;
   const float4** h_cloud_pts; const int** h_cloud_n; float* h_RT;
 };
@@ -349,6 +351,7 @@ static void ctx_free(revo_ctx* c) {
   hipHostFree(c->h_desc); hipFree(c->d_desc); hipHostFree(c->h_res); hipFree(c->d_res);
   hipHostFree(c->h_eval); hipFree(c->d_eval); hipFree(c->d_mail);
   hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8);
+  hipFree(c->d_pcl);
   hipFree(c->d_cloud_pts); hipFree(c->d_cloud_n); hipFree(c->d_RT);
   hipHostFree(c->h_cloud_pts); hipHostFree(c->h_cloud_n); hipHostFree(c->h_RT);
   hipStreamDestroy(c->stream);
@@ -510,6 +513,50 @@ extern "C" int revo_pyramid_read(revo_pyr* p, revo_plane what, int lvl, void* ds
   if (dst) {
     if (n * esz > cap) return fail(REVO_ERR_CAPACITY, "host buffer too small");
     if (n) HIPCHECK(hipMemcpy(dst, src, n * esz, hipMemcpyDeviceToHost));
+  }
+  return REVO_OK;
+}
+
+// ImgPyramidRGBD::generateColoredPcl(lvl, clrPcl, densePcl), imgpyramidrgbd.cpp:279-327.
+extern "C" int revo_pyramid_colored_pcl(revo_pyr* p, int lvl, int dense, float* dst8, size_t cap_points, size_t* count) {
+  if (!p) return fail(REVO_ERR_INVALID_ARG, "null pyramid");
+  revo_ctx* c = p->ctx;
+  HIPCHECK(hipSetDevice(c->device));
+  if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
+  if (!p->owns_fs || !p->fs->d_bgr)
+    return fail(REVO_ERR_INVALID_ARG, "batch views keep no colour image (rgbFullSize): use revo_pyramid_create");
+  { int rc = wait_ready(c, p); if (rc) return rc; }
+  std::lock_guard<std::mutex> lk(c->mu);
+  const PyrGeom& g = c->geom;
+  const size_t n0 = g.lv[0].npix, slots = (size_t)g.lv[0].w * g.lv[0].nchunk;
+  if (!c->d_pcl) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_out = take(n0 * 32), o_a = take(n0 / 4 * 3 + 3), o_b = take(n0 / 16 * 3 + 3), o_ch = take(slots * 4),
+                 o_m = take(slots * 4), o_t = take(4);
+    HIPCHECK(hipMalloc((void**)&c->d_pcl, off));
+    c->d_pcl_out = (float*)(c->d_pcl + o_out);
+    c->d_pcl_clr[0] = (uint8_t*)(c->d_pcl + o_a); c->d_pcl_clr[1] = (uint8_t*)(c->d_pcl + o_b);
+    c->d_pcl_chunk = (int*)(c->d_pcl + o_ch); c->d_pcl_mask = (unsigned*)(c->d_pcl + o_m); c->d_pcl_total = (int*)(c->d_pcl + o_t);
+  }
+  hipStream_t s = c->stream;
+  const uint8_t* clr = p->fs->d_bgr;  // the full-resolution clone (imgpyramidrgbd.cpp:51), pyrDown'ed lvl times
+  for (int l = 0; l < lvl; ++l) {
+    uint8_t* d = c->d_pcl_clr[l & 1];
+    launch_pyrdown_bgr(clr, g.lv[l].w, g.lv[l].h, d, s);
+    clr = d;
+  }
+  const int cap = (int)std::min<size_t>(dst8 ? cap_points : 0, (size_t)g.lv[lvl].npix);
+  launch_colored_pcl(g, p->fs->p, p->frame, lvl, dense ? 1 : 0, clr, c->d_pcl_chunk, c->d_pcl_mask, c->d_pcl_total,
+                     dst8 ? cap : g.lv[lvl].npix, c->d_pcl_out, s);
+  HIPCHECK(hipGetLastError());
+  int total = 0;
+  HIPCHECK(hipMemcpyAsync(&total, c->d_pcl_total, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  if (count) *count = (size_t)total;
+  if (dst8) {
+    if ((size_t)total > cap_points) return fail(REVO_ERR_CAPACITY, "host buffer too small");
+    if (total) HIPCHECK(hipMemcpy(dst8, c->d_pcl_out, (size_t)total * 32, hipMemcpyDeviceToHost));
   }
   return REVO_OK;
 }

@@ -606,15 +606,11 @@ __global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl)
   }
 }
 
-__global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl) {
-  __shared__ int s_part[1024];
-  const int f = g.frame0 + blockIdx.z, l = blockIdx.x;
-  const LevelGeom lv = g.lv[l];
-  const int n = lv.w * lv.nchunk;
-  int* a = pl.chunk[l] + (size_t)f * n;
+// exclusive scan of a[0..n) by one 1024-thread block; returns the total (valid in every thread)
+__device__ __forceinline__ int block_exclusive_scan(int* a, int n, int* s_part) {
   const int tid = threadIdx.x;
   const int per = (n + 1023) / 1024;
-  const int b = tid * per, e = min(n, b + per);
+  const int b = min(n, tid * per), e = min(n, b + per);
   int sum = 0;
   for (int i = b; i < e; ++i) sum += a[i];
   s_part[tid] = sum;
@@ -627,7 +623,88 @@ __global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl
   }
   int run = s_part[tid] - sum;  // exclusive prefix of this thread's segment
   for (int i = b; i < e; ++i) { const int c = a[i]; a[i] = run; run += c; }
-  if (tid == 1023) pl.npts[f * REVO_L + l] = s_part[1023];
+  return s_part[1023];
+}
+
+__global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl) {
+  __shared__ int s_part[1024];
+  const int f = g.frame0 + blockIdx.z, l = blockIdx.x;
+  const int n = g.lv[l].w * g.lv[l].nchunk;
+  const int total = block_exclusive_scan(pl.chunk[l] + (size_t)f * n, n, s_part);
+  if (threadIdx.x == 0) pl.npts[f * REVO_L + l] = total;
+}
+
+// ---------------------------------------------------------------------------
+// generateColoredPcl (imgpyramidrgbd.cpp:279-327), the viewer / PLY-export cloud of a keyframe:
+// the BGR image pyrDown'ed to the level (same 5x5 kernel per channel), then every pixel with a
+// usable depth (dense) or every edge pixel with a usable depth (sparse) becomes
+// (X,Y,Z,1, r/255, g/255, b/255, 1) in the reference's x-outer / y-inner order -- the same
+// chunked count / scan / write compaction as the 3-D edge list.  Off the per-frame path
+// (once per keyframe, only when a model is exported).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pyrdown_bgr(const uint8_t* __restrict__ src, int w, int h,
+                                                     uint8_t* __restrict__ dst) {
+  const int dw = w >> 1, dh = h >> 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= dw * dh) return;
+  const int x = i % dw, y = i / dw;
+  const int kk[5] = {1, 4, 6, 4, 1};
+  int acc[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, h) * w * 3;
+    int rs[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const uint8_t* px = row + (size_t)reflect101(2 * x + t - 2, w) * 3;
+      rs[0] += kk[t] * px[0]; rs[1] += kk[t] * px[1]; rs[2] += kk[t] * px[2];
+    }
+    acc[0] += kk[j] * rs[0]; acc[1] += kk[j] * rs[1]; acc[2] += kk[j] * rs[2];
+  }
+  uint8_t* o = dst + (size_t)i * 3;
+  o[0] = (uint8_t)((acc[0] + 128) >> 8); o[1] = (uint8_t)((acc[1] + 128) >> 8); o[2] = (uint8_t)((acc[2] + 128) >> 8);
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_pcl_walk(LevelGeom lv, float dmin, float dmax, const float* __restrict__ depth,
+                                                  const uint8_t* __restrict__ edges, const uint8_t* __restrict__ bgr,
+                                                  int dense, int* __restrict__ chunk, unsigned* __restrict__ cmask,
+                                                  const int* __restrict__ total, int cap, float4* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= lv.w * lv.nchunk) return;
+  const int x = i % lv.w, c = i / lv.w;
+  const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
+  const size_t slot = (size_t)x * lv.nchunk + c;
+  if (!WRITE) {
+    unsigned vm = 0;
+    for (int y = yb; y < ye; ++y) {
+      const size_t p = (size_t)y * lv.w + x;
+      if ((dense || edges[p]) && depth_ok(depth[p], dmin, dmax)) vm |= 1u << (y - yb);
+    }
+    cmask[slot] = vm;
+    chunk[slot] = __popc(vm);
+  } else {
+    if (*total > cap) return;  // the host reports REVO_ERR_CAPACITY; nothing is written past the buffer
+    int o = chunk[slot];
+    for (unsigned m = cmask[slot]; m; m &= m - 1) {
+      const int y = yb + __ffs(m) - 1;
+      const size_t p = (size_t)y * lv.w + x;
+      const float Z = depth[p];
+      const float X = __fdiv_rn(Z * ((float)x - lv.cx), lv.fx);
+      const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
+      const uint8_t* px = bgr + p * 3;
+      out[2 * o] = make_float4(X, Y, Z, 1.0f);
+      out[2 * o + 1] = make_float4(__fdiv_rn((float)px[2], 255.0f), __fdiv_rn((float)px[1], 255.0f),
+                                   __fdiv_rn((float)px[0], 255.0f), 1.0f);
+      ++o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_pcl_scan(int* chunk, int n, int* total) {
+  __shared__ int s_part[1024];
+  const int t = block_exclusive_scan(chunk, n, s_part);
+  if (threadIdx.x == 0) *total = t;
 }
 
 // ---------------------------------------------------------------------------
@@ -817,6 +894,24 @@ void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s
   hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(256), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels, 1, B), dim3(1024), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(256), 0, s, g, p);
+}
+
+void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_pyrdown_bgr, dim3(((w / 2) * (h / 2) + 255) / 256), dim3(256), 0, s, src, w, h, dst);
+}
+
+void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int lvl, int dense, const uint8_t* bgr_lvl,
+                        int* chunk, unsigned* cmask, int* total, int cap, float* out8, hipStream_t s) {
+  const LevelGeom& lv = g.lv[lvl];
+  const float* depth = p.depth[lvl] + (size_t)frame * lv.npix;
+  const uint8_t* edges = p.edges[lvl] + (size_t)frame * lv.npix;
+  const int n = lv.w * lv.nchunk;
+  dim3 grid((n + 255) / 256);
+  hipLaunchKernelGGL(k_pcl_walk<false>, grid, dim3(256), 0, s, lv, g.depth_min, g.depth_max, depth, edges, bgr_lvl, dense,
+                     chunk, cmask, total, cap, (float4*)out8);
+  hipLaunchKernelGGL(k_pcl_scan, dim3(1), dim3(1024), 0, s, chunk, n, total);
+  hipLaunchKernelGGL(k_pcl_walk<true>, grid, dim3(256), 0, s, lv, g.depth_min, g.depth_max, depth, edges, bgr_lvl, dense,
+                     chunk, cmask, total, cap, (float4*)out8);
 }
 
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {

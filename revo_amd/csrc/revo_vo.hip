@@ -90,6 +90,13 @@ extern "C" void revo_vo_destroy(revo_vo* v) {
 }
 extern "C" int revo_vo_queued(const revo_vo* v) { return v ? (int)v->queue.size() : 0; }
 extern "C" int revo_vo_num_keyframes(const revo_vo* v) { return v ? v->n_keyframes : 0; }
+// kfPyr and kfPyr->getTransKFtoWorld() (system.cpp:165-167,235-237): what the viewer / model export consume
+extern "C" int revo_vo_keyframe(const revo_vo* v, revo_pyr** kf_out, float T_w_kf[16]) {
+  if (!v || !v->kf.pyr) return REVO_ERR_INVALID_ARG;
+  if (kf_out) *kf_out = v->kf.pyr;
+  if (T_w_kf) memcpy(T_w_kf, v->kf.T_w_f.m, sizeof(float) * 16);
+  return REVO_OK;
+}
 
 // IOWrapperRGBD::generateImgPyramidFromFiles: new ImgPyramidRGBD(...) -> queue (iowrapperRGBD.cpp:279-288)
 extern "C" int revo_vo_submit(revo_vo* v, const uint8_t* bgr, size_t bgr_stride, const float* depth, size_t depth_stride,

@@ -11,9 +11,14 @@ import numpy as np
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     if len(argv) < 2:
-        print("usage: python -m revo_amd.run_tum <settings.yaml> <dataset.yaml> [device]")
+        print("usage: python -m revo_amd.run_tum <settings.yaml> <dataset.yaml> [device] [--save-model DIR]")
         return 2
-    from . import api, config, synth, tum, vo
+    from . import api, config, ply, synth, tum, vo
+    model_dir = None
+    if "--save-model" in argv:  # MapDrawer::saveModel (MapDrawer.h:97-170): outputPcl.ply + outputKf.ply
+        i = argv.index("--save-model")
+        model_dir = argv[i + 1]
+        argv = argv[:i] + argv[i + 2:]
     from .settings import OptimizerSettings
     trk_settings, use_edge_filter, sysd = config.load_settings_yaml(argv[0])
     pyr_settings, io = config.load_dataset_yaml(argv[1])
@@ -22,7 +27,9 @@ def main(argv=None):
     for ds in io["datasets"]:
         folder = os.path.join(io["main_folder"], ds)
         cam = api.CameraPyr(pyr_settings, device=device)
-        drv = vo.REVO(pyr_settings, trk_settings, cameraPyr=cam, depth_scale_factor=io["depth_scale_factor"])
+        drawer = ply.ModelExporter() if model_dir else None
+        drv = vo.REVO(pyr_settings, trk_settings, cameraPyr=cam, depth_scale_factor=io["depth_scale_factor"],
+                      mapDrawer=drawer, generate_dense_pcl=sysd["do_generate_dense_pcl"])
         t0 = time.perf_counter()
         res = drv.run(tum.frames(folder, io["associate"], bool(io["use_depth_timestamp"]),
                                  skip_first_n_frames=io["skip_first_n_frames"], read_n_images=io["read_n_images"]))
@@ -33,6 +40,9 @@ def main(argv=None):
                 f.write("\n".join(drv.tum_lines()) + "\n")
         print("-----VO Report-----\nFrames Tracked: %d\nKeyframes Tracked: %d\nframes/s (incl. PNG decode): %.1f"
               % (len(res), drv.nKeyFrames, len(res) / dt))
+        if drawer is not None:
+            out = drawer.saveModel(os.path.join(model_dir, name) if len(io["datasets"]) > 1 else model_dir)
+            print("model: %d points of %d keyframes -> %s, %s" % (drawer.nPts, len(drawer.vpKfsF), out[0], out[1]))
         gt_file = os.path.join(folder, "groundtruth.txt")
         if os.path.exists(gt_file):
             gt = tum.read_groundtruth_positions(gt_file)

@@ -19,7 +19,8 @@ from .settings import TrackerSettings
 
 
 class REVO:
-    def __init__(self, settingsPyr, settingsTracker=None, device=0, cameraPyr=None, depth_scale_factor=None):
+    def __init__(self, settingsPyr, settingsTracker=None, device=0, cameraPyr=None, depth_scale_factor=None,
+                 mapDrawer=None, generate_dense_pcl=False):
         self.settingsPyr = settingsPyr
         self.settingsTracker = settingsTracker or TrackerSettings()
         self.camPyr = cameraPyr or api.CameraPyr(settingsPyr, device=device)
@@ -28,6 +29,10 @@ class REVO:
         check(_lib.lib().revo_vo_create(self.camPyr._h, C.byref(self._h)))
         self.poses = []  # (timestamp, 4x4 curr->world)
         self.depth_scale_factor = depth_scale_factor  # set: depth arrives as raw uint16
+        # ply.ModelExporter (MapDrawer's model half): gets one coloured cloud + pose per keyframe like
+        # system.cpp:162-168,232-238; generate_dense_pcl is DO_GENERATE_DENSE_PCL
+        self.mpMapDrawer = mapDrawer
+        self.generate_dense_pcl = bool(generate_dense_pcl)
 
     def __del__(self):
         try:
@@ -67,7 +72,19 @@ class REVO:
         check(_lib.lib().revo_vo_track_next(self._h, pose.ctypes.data_as(f32p), C.byref(kf), C.byref(ts)))
         M = pose.reshape(4, 4).T.copy()
         self.poses.append((ts.value, M))
+        if kf.value and self.mpMapDrawer is not None:
+            kfPyr, T_w_kf = self.keyframe()
+            self.mpMapDrawer.addPclAndKfPoseToQueue(kfPyr.generateColoredPcl(0, self.generate_dense_pcl), T_w_kf)
         return M, bool(kf.value)
+
+    def keyframe(self):
+        """(kfPyr, kfPyr->getTransKFtoWorld()); the pyramid is borrowed -- valid until the next track_next."""
+        h = vp()
+        T = np.empty(16, np.float32)
+        check(_lib.lib().revo_vo_keyframe(self._h, C.byref(h), T.ctypes.data_as(f32p)))
+        pyr = api.ImgPyramidRGBD(self.settingsPyr, self.camPyr, _handle=h, _owned=False)
+        pyr._vo = self  # keep the driver (owner of the handle) alive
+        return pyr, T.reshape(4, 4).T.copy()
 
     def push(self, bgr, depth, timestamp):
         self.submit(bgr, depth, timestamp)

@@ -1,7 +1,6 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest.log
-timeout 200 python bench.py --input-cache /tmp/revo_in --cpu-baseline off --single-stream-frames 0 --no-overlap --steps 10 > gpurun_out/bench_exp.log 2>&1
-grep -E "passed|failed" gpurun_out/pytest.log
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest.log
+tail -15 gpurun_out/pytest.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+python bench.py 2>&1 | tail -2 | tee gpurun_out/bench.log

@@ -47,6 +47,11 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 9; ++i) std::printf(" %.9g", R.m[i]);
   std::printf("\nT %.9g %.9g %.9g\nerr %.9g\nstatus %d\nn0 %zu\n", T.v[0], T.v[1], T.v[2], error, status,
               currPyr->return3DEdges(0).size() / 4);
+  // generateColoredPcl(lvl, clrPcl, dense), imgpyramidrgbd.cpp:279-327: count and a checksum of the floats
+  const std::vector<float> pcl = kfPyr->generateColoredPcl(1, true);
+  double sum = 0;
+  for (float v : pcl) sum += v;
+  std::printf("pcl %zu %.9g\n", pcl.size() / 8, sum);
   // error behaviour: tracking against a non-keyframe must fail like "optimizationStructure not built!"
   try {
     tracker.trackFrames(R, T, error, currPyr, kfPyr);

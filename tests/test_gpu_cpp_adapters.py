@@ -45,5 +45,7 @@ def test_cpp_adapter_host_matches_python_host(tmp_path):
     assert int(vals["status"][0]) == st2
     assert int(vals["n0"][0]) == cur.return3DEdges(0).shape[0]
     assert vals["notkf"] == ["error"]
+    pcl = ref.generateColoredPcl(1, True)
+    assert int(vals["pcl"][0]) == len(pcl) and abs(float(vals["pcl"][1]) - float(pcl.astype(np.float64).sum())) < 1e-3
     er, et = synth.pose_error(R_cpp, T_cpp, pair["T_ref_curr"])
     assert er < 3e-3 and et < 5e-3

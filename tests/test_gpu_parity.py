@@ -251,6 +251,37 @@ def test_assess_tracking_quality_parity(api, ro, pair640):
     assert np.array_equal(h_g, h_o) and np.array_equal(o_g, o_o) and st_g == st_o
 
 
+def test_colored_pcl_bit_exact(api, ro, pair640):
+    """ImgPyramidRGBD::generateColoredPcl (imgpyramidrgbd.cpp:279-327): the keyframe cloud for the viewer /
+    PLY export, sparse (edges) and dense, on every level; also after keyframe promotion and for a
+    second pyramid (shared scratch), and its error paths."""
+    import ctypes as C
+    from revo_amd import _lib
+    s, pair = pair640
+    cam = api.CameraPyr(s)
+    for tag in ("ref", "curr"):
+        bgr, depth = pair[tag]
+        gp = api.ImgPyramidRGBD(s, cam, bgr, depth, 1.0)
+        op = ro.Pyramid(s, bgr, depth, 1.0)
+        if tag == "curr":
+            gp.makeKeyframe()
+        for lvl in range(s.nLevels()):
+            for dense in (False, True):
+                g = gp.generateColoredPcl(lvl, dense)
+                assert_same("clrpcl_%s_%d_%d" % (tag, lvl, dense), g, op.generateColoredPcl(lvl, dense))
+        assert np.array_equal(gp.generateColoredPcl(1, False)[:, :4], gp.return3DEdges(1))
+        compare_pyramid("clrpcl_after_" + tag, gp, op, s, False)  # the export leaves the pyramid untouched
+    n = C.c_size_t()
+    buf = np.empty((10, 8), np.float32)
+    L = _lib.lib()
+    assert L.revo_pyramid_colored_pcl(gp._h, 0, 1, None, 0, C.byref(n)) == 0 and n.value > 200000  # count only
+    assert L.revo_pyramid_colored_pcl(gp._h, 0, 0, buf.ctypes.data_as(_lib.f32p), 10, C.byref(n)) == -5  # capacity
+    assert n.value == len(gp.return3DEdges(0))
+    with pytest.raises(api.RevoError) as e:
+        gp.generateColoredPcl(5, False)
+    assert e.value.code == -6
+
+
 def test_error_behaviour(api, pair640):
     s, pair = pair640
     cam = api.CameraPyr(s)

@@ -38,9 +38,18 @@ def test_vo_matches_oracle_trajectory_and_keyframes():
     assert d_rot < 5e-4 and d_tr < 5e-4
     assert abs(ate_g - ate_o) < 1e-3 and ate_g < 0.01
     # the pipelined driver (one frame of look-ahead, like the reference's IO thread) gives the same bits
-    gpu2 = vo.REVO(s)
+    from revo_amd import ply
+    drawer = ply.ModelExporter()  # MapDrawer's model half: one coloured cloud + pose per keyframe
+    gpu2 = vo.REVO(s, mapDrawer=drawer)
     res2 = gpu2.run([(f[0], f[1], f[2]) for f in frames])
     assert all(np.array_equal(a, b[0]) for a, b in zip(est_g, res2)) and gpu2.nKeyFrames == gpu.nKeyFrames
+    assert len(drawer.pclKfHost) == gpu2.nKeyFrames == len(drawer.vpKfsF)
+    # keyframe k is frame kf_g[k]-1 (the previous frame is promoted, system.cpp:205-215); frame 0 is the first
+    kf_frames = [0] + [i - 1 for i in kf_g[1:]]
+    for k, fi in enumerate(kf_frames):
+        o = ro.Pyramid(s, frames[fi][0], frames[fi][1])
+        assert np.array_equal(drawer.pclKfHost[k], o.generateColoredPcl(0, False)), k
+        assert np.array_equal(drawer.vpKfsF[k], est_g[fi]), k  # getTransKFtoWorld == that frame's world pose
     lines = gpu.tum_lines()  # system.cpp:76-80
     assert len(lines) == len(frames) and len(lines[3].split()) == 8
     q = np.array(lines[3].split()[4:], np.float64)
@@ -65,7 +74,12 @@ def test_run_tum_cli_on_a_synthetic_tum_dataset(tmp_path, monkeypatch):
     (tmp_path / "settings.yaml").write_text("%YAML:1.0\nCHECK_TRACKING_RESULTS: 1\nCHECK_INIT_VALUES: 1\nUSE_EDGE_FILTER: 1\n"
                                             "N_FRAMES_HIST_VOTING: 3\nDO_OUTPUT_POSES: 1\n")
     monkeypatch.chdir(tmp_path)
-    assert run_tum.main([str(tmp_path / "settings.yaml"), str(tmp_path / "dataset.yaml")]) == 0
+    assert run_tum.main([str(tmp_path / "settings.yaml"), str(tmp_path / "dataset.yaml"), "--save-model",
+                         str(tmp_path / "model")]) == 0
+    from revo_amd import ply
+    v, _, _ = ply.read_ply_vertices(str(tmp_path / "model" / "outputPcl.ply"))  # MapDrawer::saveModel
+    kv, ke, ne = ply.read_ply_vertices(str(tmp_path / "model" / "outputKf.ply"))
+    assert len(v) > 1000 and len(kv) % 5 == 0 and len(ke) == ne == 9 * (len(kv) // 5) - 1
     lines = (tmp_path / "poses_rgbd_dataset_synth.txt").read_text().strip().splitlines()
     assert len(lines) == 16
     est = []
