@@ -772,6 +772,12 @@ extern "C" int revo_tracker_clear_past(revo_ctx* c) {  // tracker.cpp:248-257
   }
   return REVO_OK;
 }
+// a new REVO::start builds a new TrackerNew (system.cpp:107): empty lists.  Internal (revo_vo.hip).
+extern "C" void revo_tracker_reset_past_(revo_ctx* c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  while (!c->past.empty()) { c->past_pool.push_back(c->past.front()); c->past.pop_front(); }
+}
 extern "C" int revo_tracker_past_size(const revo_ctx* c) { return c ? (int)c->past.size() : 0; }
 
 // -------------------------------------------------------------------- batch --

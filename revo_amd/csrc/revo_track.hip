@@ -189,49 +189,82 @@ __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, cons
   qo[0] = w; qo[1] = x; qo[2] = y; qo[3] = z;
 }
 
+// std::pow(lambdaFailFac, incTry) (optimizer.cpp:303: float base, int exponent -> double pow).  The
+// library pow in double costs ~100 VGPRs on the decision path; for an integer exponent the same
+// correctly-rounded value comes out of a double-double running product (Dekker two-product with
+// fma: error ~2^-100 before the final rounding).  Exact for the default factor 2.
+__device__ __forceinline__ double powi_dd(double b, int n) {
+  double hi = 1.0, lo = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double p = hi * b;
+    const double e = __builtin_fma(hi, b, -p);
+    const double l = lo * b + e;
+    const double h2 = p + l;
+    lo = l - (h2 - p);
+    hi = h2;
+  }
+  return hi + lo;
+}
+
 // Damped 6x6 solve A(1+lambda on the diagonal) x = b in double (LDL^T, no
 // pivoting: A = J^T W J / n is positive semi-definite).  The reference solves
 // the same system with Eigen's float LDLT (optimizer.cpp:258-262); a zero /
 // invalid pivot contributes 0 like Eigen's pseudo-inverse of D.
 // Aacc: 21 upper-triangle entries (row-major) then 6 rhs.
 #define AIDX(i, j) ((i) * 6 - ((i) * ((i)-1)) / 2 + ((j) - (i)))  // upper triangle, i <= j
-__device__ __forceinline__ void solve6(const double* Aacc, float lambda, float* x) {
+__device__ __forceinline__ double bcast_lane(double v, int src) {  // wave-uniform copy of lane src's value (v_readlane)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// Row-parallel form: lane i (< 6) owns row i of A and of L; the pivots and the row-j entries a
+// step needs are broadcast with v_readlane.  Every element sees exactly the operations of the
+// textbook serial loops, in the same order (k ascending), so the result is bit-identical to
+// them -- but the serial chain is 6 steps instead of 21 and a lane keeps 12 doubles instead of 33.
+// Must be called by all 64 lanes of a wave (lanes >= 6 shadow row 5); x is wave-uniform.
+__device__ __forceinline__ void solve6(const double* Aacc, float lambda, float* x, int lane) {
   const double damp = (double)(1.0f + lambda);
-  double L[6][6], D[6], Dinv[6];
+  const int row = lane < 6 ? lane : 5;
+  double Arow[6], Lrow[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int lo = row < c ? row : c, hi = row < c ? c : row;
+    Arow[c] = Aacc[AIDX(lo, hi)];
+    Lrow[c] = 0.0;
+  }
+  double v = Aacc[21 + row];  // rhs of this row, becomes y then x
+  double D[6], Dinv_mine = 0.0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double dj = Aacc[AIDX(j, j)] * damp;
+    double a = (row == j) ? Arow[j] * damp : Arow[j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * D[k];
+    for (int k = 0; k < j; ++k) a -= Lrow[k] * bcast_lane(Lrow[k], j) * D[k];
+    const double dj = bcast_lane(a, j);
     D[j] = dj;
-    Dinv[j] = (dj > 1e-300) ? 1.0 / dj : 0.0;
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double v = Aacc[AIDX(j, i)];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
-      L[i][j] = v * Dinv[j];
-    }
+    const double dinv = (dj > 1e-300) ? 1.0 / dj : 0.0;
+    if (row == j) Dinv_mine = dinv;
+    if (row > j) Lrow[j] = a * dinv;
   }
-  double y[6];
+  // forward substitution L y = b (k ascending per row), then y *= D^-1
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double v = Aacc[21 + i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
-    y[i] = v;
+  for (int k = 0; k < 5; ++k) {
+    const double yk = bcast_lane(v, k);
+    if (row > k) v -= Lrow[k] * yk;
   }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] *= Dinv[i];
+  v *= Dinv_mine;
+  // backward substitution L^T x = y: x_i = y_i - sum_{k>i} L[k][i] x_k, k ascending
+  double xs[6];
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
-    double v = y[i];
+    const double term = Lrow[i] * v;  // lane k > i: L[k][i] * x_k (x_k is final on those lanes)
+    double acc = bcast_lane(v, i);
 #pragma unroll
-    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * y[k];
-    y[i] = v;
+    for (int k = i + 1; k < 6; ++k) acc -= bcast_lane(term, k);
+    xs[i] = acc;
+    if (row == i) v = acc;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = (float)y[i];
+  for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
 }
 
 // 64-lane reduce-scatter butterfly: 32 per-lane values -> lane L ends with the
@@ -358,10 +391,20 @@ __device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch
   acc[29] += good ? 1.0f : 0.0f;
 }
 
+// Register budget.  k_track shares every CU with the pyramid-build kernels of the next batch
+// (bench.py / revo_batch_*: build k+1 overlaps track k).  With the compiler's default budget for a
+// 512-thread block (256 VGPRs) the kernel took 246, i.e. 2 waves x 246 = 96 % of each SIMD's
+// register file: a 32-VGPR k_canny_nms wave could not become resident next to it and the build
+// ran 2.3x slower while a tracker was in flight (profiles/r01_overlap_*.txt).  168 VGPRs (the
+// 3-waves-per-SIMD budget) is reached without spills once the points kept in registers are cut to
+// 4 per thread, the 6x6 solve is row-parallel and pow() is an integer power; that leaves 176
+// VGPRs per SIMD to the co-runners.  (128 needs spills on the decision path: slower overall.)
 #ifndef TRACK_MAXP
-#define TRACK_MAXP 8                  // points of a level kept in registers per thread
+#define TRACK_MAXP 4                  // points of a level kept in registers per thread; the rest streams from L2
 #endif
-#define TRACK_LDS_DT_BYTES 76800        // DT planes up to 160x120 f32 are staged in LDS; 2 x (75 KB + 1.4 KB) fit one CU
+#ifndef TRACK_WAVES_PER_EU
+#define TRACK_WAVES_PER_EU 3
+#endif
 
 // Two points in flight: both projections, then all 24 DT gathers, then the math.
 template <typename PTR>
@@ -432,18 +475,21 @@ __device__ __forceinline__ float cost_level(const f4v* preg, gf4p pts, int first
 }
 
 // ---- the kernel ---------------------------------------------------------------
-__global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restrict__ descs, TrackParams prm,
+#define TRACK_OCC __attribute__((amdgpu_waves_per_eu(TRACK_WAVES_PER_EU, TRACK_WAVES_PER_EU)))
+__global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDesc* __restrict__ descs, TrackParams prm,
                                                          revo_pair_result* __restrict__ out, EvalOut* __restrict__ eval_out,
                                                          u64* __restrict__ mail, int n_pairs, int cluster) {
   __shared__ Ctrl s_ctrl;
   __shared__ W0State s;
   __shared__ float s_part[NWAVES][32];
-  extern __shared__ __attribute__((aligned(16))) float s_dt[];  // TRACK_LDS_DT_BYTES: coarse-level DT plane
   // XCD-affine mapping: all members of a pair share blockIdx % 8 (speed only, never correctness)
   const int b = blockIdx.x;
   const int pair = (b / (8 * cluster)) * 8 + (b % 8);
   const int member = (b / 8) % cluster;
   if (pair >= n_pairs) return;
+#ifdef REVO_TRACK_SETPRIO
+  __builtin_amdgcn_s_setprio(REVO_TRACK_SETPRIO);
+#endif
   const PairDesc& d = descs[pair];
   u64* mail_pair = mail + (size_t)pair * 2 * cluster * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -451,7 +497,6 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
   const int first = member * TRACK_THREADS + tid;
   unsigned epoch = 0;
   int cur_level = -1;
-  bool dt_in_lds = false;
   f4v preg[TRACK_MAXP > 0 ? TRACK_MAXP : 1];
 #pragma unroll
   for (int k = 0; k < TRACK_MAXP; ++k) preg[k] = f4v{0.f, 0.f, 1.f, 1.f};
@@ -526,30 +571,22 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
 #endif
 
     if (l != cur_level) {
-      // Level entry (block-uniform): this thread's points go to registers for every evaluation
-      // of the level -- only the pose changes between them (optimizer.cpp:250-305) -- and a
-      // DT plane that fits is staged in LDS, so coarse-level evaluations never wait on HBM/L2.
+      // Level entry (block-uniform): this thread's first points go to registers for every evaluation
+      // of the level -- only the pose changes between them (optimizer.cpp:250-305).  (Staging the
+      // coarse DT planes in LDS was measured at 0 % gain -- they sit in L2 -- and cost 76.8 KB of
+      // LDS per CU that the co-running build kernels need.)
       cur_level = l;
 #pragma unroll
       for (int k = 0; k < TRACK_MAXP; ++k) {
         const int i = first + k * stride;
         preg[k] = (i < N) ? pts[i] : f4v{0.f, 0.f, 1.f, 1.f};
       }
-      dt_in_lds = (size_t)w * h * sizeof(float) <= TRACK_LDS_DT_BYTES;
-      if (dt_in_lds) {
-        const int n4 = (w * h) / 4;
-        gf4p src = (gf4p)d.dt[l];
-        f4v* dst = reinterpret_cast<f4v*>(s_dt);
-        for (int i = tid; i < n4; i += TRACK_THREADS) dst[i] = src[i];
-        __syncthreads();
-      }
     }
     const float ed = prm.edge_distance[l];
     const bool filt = prm.use_edge_filter != 0;
     if (mode == MODE_COST) {
       // TrackerNew::evalCostFunction, tracker.cpp:357-393: nearest-pixel DT lookup
-      float cost = dt_in_lds ? cost_level(preg, pts, first, stride, N, (const float*)s_dt, w, h, R, T, fx, fy, cx, cy, ed, filt)
-                             : cost_level(preg, pts, first, stride, N, dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
+      float cost = cost_level(preg, pts, first, stride, N, dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) cost += __shfl_xor(cost, m);
       if (lane < 32) s_part[wave][lane] = (lane == 0) ? cost : 0.0f;
@@ -559,10 +596,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
       float acc[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-      if (dt_in_lds)
-        eval_level(preg, pts, first, stride, N, (const float*)s_dt, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
-      else
-        eval_level(preg, pts, first, stride, N, dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
+      eval_level(preg, pts, first, stride, N, dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
       butterfly_step<16, 32>(acc, lane);
       butterfly_step<8, 16>(acc, lane);
       butterfly_step<4, 8>(acc, lane);
@@ -699,7 +733,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
             if (!(s.incsq > prm.step_size_min[l])) {
               level_done = true;
             } else {
-              lambda = (lambda == 0.0f) ? 0.2f : (float)((double)lambda * pow((double)prm.lambda_fail_fac, (double)incTry));
+              lambda = (lambda == 0.0f) ? 0.2f : (float)((double)lambda * powi_dd((double)prm.lambda_fail_fac, incTry));
               new_candidate = true;  // same outer iteration, incTry keeps counting
             }
           }
@@ -731,7 +765,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
           }
         } else if (new_candidate) {  // optimizer.cpp:258-269
           float inc[6], qn[4], tn[3], Rn[9];
-          solve6(s.Aacc, lambda, inc);
+          solve6(s.Aacc, lambda, inc, lane);
           incTry += 1;
           const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
           se3_exp_mul(inc, q, t, qn, tn);
@@ -798,7 +832,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) k_track(const PairDesc* __restr
 
 int track_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_track, TRACK_THREADS, TRACK_LDS_DT_BYTES) != hipSuccess) nb = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_track, TRACK_THREADS, 0) != hipSuccess) nb = 1;
   return nb < 1 ? 1 : nb;
 }
 
@@ -807,6 +841,6 @@ void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_res
   // granules carry epochs that restart at 1 every launch: zero the mailbox first (stream ordered)
   if (cluster > 1) hipMemsetAsync(d_mail, 0, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32, s);
   const int groups = (n_pairs + 7) / 8;
-  hipLaunchKernelGGL(k_track, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), TRACK_LDS_DT_BYTES, s, d_descs, prm, d_out,
+  hipLaunchKernelGGL(k_track, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, d_descs, prm, d_out,
                      d_eval, (u64*)d_mail, n_pairs, cluster);
 }

@@ -2,11 +2,13 @@
 // Host-only code: the device work is what revo_pyramid_* / revo_tracker_* enqueue.
 #include <cstring>
 #include <deque>
+#include <mutex>
 
 #include "../../include/revo_hip.h"
 
 extern "C" void revo_ctx_retain_(revo_ctx*);
 extern "C" void revo_ctx_release_(revo_ctx*);
+extern "C" void revo_tracker_reset_past_(revo_ctx*);
 
 namespace {
 struct M4 {  // column-major 4x4, Eigen::Matrix4f storage
@@ -62,6 +64,7 @@ struct Frame { revo_pyr* pyr; double ts; M4 T_w_f; };
 struct revo_vo {
   revo_ctx* ctx;
   std::deque<Frame> queue;  // mPyrQueue, iowrapperRGBD.h:166-167
+  std::mutex qmu;           // mtx of the reference's queue: submit may run on an IO thread (system.cpp:96)
   Frame kf{nullptr, 0, M4::identity()}, prev{nullptr, 0, M4::identity()};
   Pose last, before_last;
   M4 T_NM1_N = M4::identity();
@@ -77,6 +80,9 @@ extern "C" int revo_vo_create(revo_ctx* ctx, revo_vo** out) {
   v->ctx = ctx;
   revo_ctx_retain_(ctx);
   v->hist_level = revo_ctx_histogram_level(ctx);
+  // REVO::start makes a fresh TrackerNew (system.cpp:107): a driver never votes against the clouds
+  // another driver on the same context left behind
+  revo_tracker_reset_past_(ctx);
   *out = v;
   return REVO_OK;
 }
@@ -88,7 +94,11 @@ extern "C" void revo_vo_destroy(revo_vo* v) {
   revo_ctx_release_(v->ctx);
   delete v;
 }
-extern "C" int revo_vo_queued(const revo_vo* v) { return v ? (int)v->queue.size() : 0; }
+extern "C" int revo_vo_queued(const revo_vo* v) {
+  if (!v) return 0;
+  std::lock_guard<std::mutex> lk(const_cast<revo_vo*>(v)->qmu);
+  return (int)v->queue.size();
+}
 extern "C" int revo_vo_num_keyframes(const revo_vo* v) { return v ? v->n_keyframes : 0; }
 // kfPyr and kfPyr->getTransKFtoWorld() (system.cpp:165-167,235-237): what the viewer / model export consume
 extern "C" int revo_vo_keyframe(const revo_vo* v, revo_pyr** kf_out, float T_w_kf[16]) {
@@ -105,7 +115,7 @@ extern "C" int revo_vo_submit(revo_vo* v, const uint8_t* bgr, size_t bgr_stride,
   Frame f{nullptr, ts, M4::identity()};
   const int rc = revo_pyramid_create(v->ctx, bgr, bgr_stride, depth, depth_stride, ts, &f.pyr);
   if (rc) return rc;
-  v->queue.push_back(f);
+  { std::lock_guard<std::mutex> lk(v->qmu); v->queue.push_back(f); }
   return REVO_OK;
 }
 
@@ -115,15 +125,20 @@ extern "C" int revo_vo_submit_u16(revo_vo* v, const uint8_t* bgr, size_t bgr_str
   Frame f{nullptr, ts, M4::identity()};
   const int rc = revo_pyramid_create_u16(v->ctx, bgr, bgr_stride, depth_raw, depth_stride, depth_scale_factor, ts, &f.pyr);
   if (rc) return rc;
-  v->queue.push_back(f);
+  { std::lock_guard<std::mutex> lk(v->qmu); v->queue.push_back(f); }
   return REVO_OK;
 }
 
 // one body of the while loop of REVO::start (system.cpp:128-284)
 extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_out, double* ts_out) {
-  if (!v || v->queue.empty()) return REVO_ERR_INVALID_ARG;
-  Frame curr = v->queue.front();
-  v->queue.pop_front();
+  if (!v) return REVO_ERR_INVALID_ARG;
+  Frame curr;
+  {
+    std::lock_guard<std::mutex> lk(v->qmu);
+    if (v->queue.empty()) return REVO_ERR_INVALID_ARG;
+    curr = v->queue.front();
+    v->queue.pop_front();
+  }
   int rc, new_kf = 0, status = 0;
   const M4 I = M4::identity();
   if (ts_out) *ts_out = curr.ts;

@@ -4,7 +4,8 @@
 The reference runs a producer thread that builds pyramids into a queue and a consumer loop that
 tracks the oldest one.  `submit` is the producer side (asynchronous on the device: the pyramid of
 frame N+1 is built while frame N is tracked), `track_next` one body of the consumer loop.  `push`
-is submit + track_next (no look-ahead); `run` keeps one frame of look-ahead like the reference.
+is submit + track_next (no look-ahead); `run` drives both sides like the reference: a producer
+(IO) thread feeding a bounded queue and the consumer loop on the calling thread.
 
 Single stream = one GPU (frame N's initial pose and keyframe depend on frame N-1); see
 api.BatchTracker for the throughput mode.
@@ -90,20 +91,63 @@ class REVO:
         self.submit(bgr, depth, timestamp)
         return self.track_next()
 
-    def run(self, frames):
-        """frames: iterable of (bgr, depth, timestamp).  One frame of look-ahead: the next pyramid
-        is being built on the device while the current frame is tracked."""
-        out = []
-        it = iter(frames)
-        try:
-            f = next(it)
-        except StopIteration:
-            return out
-        self.submit(*f[:3])
-        for f in it:
+    def run(self, frames, io_thread=True, max_queue=4):
+        """frames: iterable of (bgr, depth, timestamp).
+
+        io_thread=True is the reference's threading (system.cpp:96, iowrapperRGBD.cpp:279-288): a
+        producer thread builds pyramids into the queue (host copy into pinned staging + asynchronous
+        device build) while this thread runs the consumer loop.  io_thread=False keeps one frame of
+        look-ahead on a single thread.  Both give the same bits as `push` per frame."""
+        if not io_thread:
+            out = []
+            it = iter(frames)
+            try:
+                f = next(it)
+            except StopIteration:
+                return out
             self.submit(*f[:3])
+            for f in it:
+                self.submit(*f[:3])
+                out.append(self.track_next())
             out.append(self.track_next())
-        out.append(self.track_next())
+            return out
+        import threading
+        slots = threading.Semaphore(max_queue)  # bounds the pyramids in flight (each holds its device planes)
+        ready = threading.Semaphore(0)
+        state = {"n": 0, "done": False, "err": None}
+
+        def producer():
+            try:
+                for f in frames:
+                    slots.acquire()
+                    if state["err"] is not None:
+                        break
+                    self.submit(*f[:3])
+                    state["n"] += 1
+                    ready.release()
+            except BaseException as e:  # surfaced on the consumer thread
+                state["err"] = e
+            state["done"] = True
+            ready.release()
+
+        th = threading.Thread(target=producer, name="revo-io", daemon=True)
+        th.start()
+        out = []
+        try:
+            while True:
+                ready.acquire()
+                if len(out) == state["n"] and state["done"]:
+                    break
+                out.append(self.track_next())
+                slots.release()
+        except BaseException as e:
+            state["err"] = state["err"] or e
+            slots.release()
+            raise
+        finally:
+            th.join()
+        if state["err"] is not None:
+            raise state["err"]
         return out
 
     def tum_lines(self):

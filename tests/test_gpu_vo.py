@@ -44,6 +44,10 @@ def test_vo_matches_oracle_trajectory_and_keyframes():
     res2 = gpu2.run([(f[0], f[1], f[2]) for f in frames])
     assert all(np.array_equal(a, b[0]) for a, b in zip(est_g, res2)) and gpu2.nKeyFrames == gpu.nKeyFrames
     assert len(drawer.pclKfHost) == gpu2.nKeyFrames == len(drawer.vpKfsF)
+    # single-thread look-ahead, and a second driver on the same context (fresh tracker state, system.cpp:107)
+    gpu3 = vo.REVO(s, cameraPyr=gpu2.camPyr)
+    res3 = gpu3.run([(f[0], f[1], f[2]) for f in frames], io_thread=False)
+    assert all(np.array_equal(a, b[0]) for a, b in zip(est_g, res3)) and [i for i, r in enumerate(res3) if r[1]] == kf_g
     # keyframe k is frame kf_g[k]-1 (the previous frame is promoted, system.cpp:205-215); frame 0 is the first
     kf_frames = [0] + [i - 1 for i in kf_g[1:]]
     for k, fi in enumerate(kf_frames):
