@@ -120,10 +120,17 @@ void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStrea
 void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int lvl, int dense, const uint8_t* bgr_lvl,
                         int* chunk, unsigned* cmask, int* total, int cap, float* out8, hipStream_t s);
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
+// epoch_io: per-mailbox epoch counter kept by the owner of d_mail (zero it together with the mailbox)
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
-                  int n_pairs, unsigned long long* d_mail, int cluster, hipStream_t s);
+                  int n_pairs, unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
+void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
+                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
 int track_blocks_per_cu();  // occupancy query of k_track (advisory)
 void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
-void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds,
-                 const float4* const* d_cloud_pts, const int* const* d_cloud_n, const float* d_RT /*n x 12*/,
-                 int* d_marks /*npix*/, int* d_hist8 /*hist[4], overlaps[4]*/, int use_orig_edges, hipStream_t s);
+// past clouds of the quality vote (tracker.cpp:138-176): pose of cloud c relative to the current frame
+// (R column-major 9 + T 3), its points and its on-device count
+struct VoteArgs { float RT[3][12]; const float4* pts[3]; const int* n[3]; };
+void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds, const VoteArgs& va,
+                 int* d_marks /*npix, all-zero in/out*/, int* d_hist8 /*all-zero in/out*/, unsigned* d_done /*zero in/out*/,
+                 int* h_out8 /*pinned host: hist[4], overlaps[4]*/, int use_orig_edges, hipStream_t s);
+void launch_copy_cloud(float4* dst, const float4* src, int* dst_n, const int* src_n, hipStream_t s);

@@ -93,18 +93,19 @@ struct revo_ctx {
   std::vector<FrameSet*> pool;  // free single-frame FrameSets
   std::vector<Past> past_pool;  // recycled past-cloud buffers (no hipMalloc per frame)
   // single-pair tracker scratch
-  PairDesc* h_desc; PairDesc* d_desc;
-  revo_pair_result* h_res; revo_pair_result* d_res;
-  EvalOut* h_eval; EvalOut* d_eval;
+  // the kernel reads the descriptor from its argument segment and writes the result straight into
+  // pinned host memory: one launch + one sync per trackFrames, no copies on the stream
+  PairDesc* h_desc;
+  revo_pair_result* h_res;
+  EvalOut* h_eval;
   unsigned long long* d_mail;   // cluster mailbox of the single-pair path
+  unsigned mail_epoch = 0;      // next free epoch window of d_mail (launch_track_one)
   int num_cus, blocks_per_cu;
   // vote
   std::deque<Past> past;
-  int* d_marks; int* d_hist8; int* h_hist8;
+  int* d_marks; int* d_hist8; int* h_hist8; unsigned* d_vote_done;
   // coloured point cloud (generateColoredPcl), allocated on first use
   char* d_pcl = nullptr; float* d_pcl_out; uint8_t* d_pcl_clr[2]; int* d_pcl_chunk; unsigned* d_pcl_mask; int* d_pcl_total;
-  const float4** d_cloud_pts; const int** d_cloud_n; float* d_RT;
-  const float4** h_cloud_pts; const int** h_cloud_n; float* h_RT;
 };
 
 struct revo_pyr {
@@ -124,6 +125,7 @@ struct revo_batch {
   std::vector<revo_pyr> views;
   PairDesc* h_descs; PairDesc* d_descs;
   unsigned long long* d_mail;
+  unsigned mail_epoch = 0;
   int cluster;
   hipStream_t stream;
   hipEvent_t ev0, ev1, ev_upload;
@@ -315,27 +317,24 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHECK(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
-  HIPCHECK(hipMalloc((void**)&c->d_desc, sizeof(PairDesc)));
   HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result)));
-  HIPCHECK(hipMalloc((void**)&c->d_res, sizeof(revo_pair_result)));
   HIPCHECK(hipHostMalloc((void**)&c->h_eval, sizeof(EvalOut)));
-  HIPCHECK(hipMalloc((void**)&c->d_eval, sizeof(EvalOut)));
   hipDeviceProp_t prop;
   HIPCHECK(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount;
   c->blocks_per_cu = std::min(track_blocks_per_cu(), 2);
   HIPCHECK(hipMalloc((void**)&c->d_mail, mail_bytes(1, TRACK_MAX_CLUSTER)));
+  HIPCHECK(hipMemset(c->d_mail, 0, mail_bytes(1, TRACK_MAX_CLUSTER)));
   size_t maxpix = 0;
   for (int l = 0; l < c->geom.n_levels; ++l) maxpix = std::max(maxpix, (size_t)c->geom.lv[l].npix);
   HIPCHECK(hipMalloc((void**)&c->d_marks, sizeof(int) * maxpix));
   HIPCHECK(hipMalloc((void**)&c->d_hist8, sizeof(int) * 8));
+  HIPCHECK(hipMalloc((void**)&c->d_vote_done, sizeof(unsigned)));
+  // the vote kernels leave their scratch clean: zero it once
+  HIPCHECK(hipMemset(c->d_marks, 0, sizeof(int) * maxpix));
+  HIPCHECK(hipMemset(c->d_hist8, 0, sizeof(int) * 8));
+  HIPCHECK(hipMemset(c->d_vote_done, 0, sizeof(unsigned)));
   HIPCHECK(hipHostMalloc((void**)&c->h_hist8, sizeof(int) * 8));
-  HIPCHECK(hipMalloc((void**)&c->d_cloud_pts, sizeof(void*) * 4));
-  HIPCHECK(hipMalloc((void**)&c->d_cloud_n, sizeof(void*) * 4));
-  HIPCHECK(hipMalloc((void**)&c->d_RT, sizeof(float) * 12 * 4));
-  HIPCHECK(hipHostMalloc((void**)&c->h_cloud_pts, sizeof(void*) * 4));
-  HIPCHECK(hipHostMalloc((void**)&c->h_cloud_n, sizeof(void*) * 4));
-  HIPCHECK(hipHostMalloc((void**)&c->h_RT, sizeof(float) * 12 * 4));
   *out = c;
   return REVO_OK;
 }
@@ -348,12 +347,9 @@ static void ctx_free(revo_ctx* c) {
   for (auto& p : c->past_pool) { hipFree(p.d_pts); hipFree(p.d_n); }
   hipStreamDestroy(c->build_stream);
   for (FrameSet* fs : c->pool) frameset_destroy(fs);
-  hipHostFree(c->h_desc); hipFree(c->d_desc); hipHostFree(c->h_res); hipFree(c->d_res);
-  hipHostFree(c->h_eval); hipFree(c->d_eval); hipFree(c->d_mail);
-  hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8);
+  hipHostFree(c->h_desc); hipHostFree(c->h_res); hipHostFree(c->h_eval); hipFree(c->d_mail);
+  hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8); hipFree(c->d_vote_done);
   hipFree(c->d_pcl);
-  hipFree(c->d_cloud_pts); hipFree(c->d_cloud_n); hipFree(c->d_RT);
-  hipHostFree(c->h_cloud_pts); hipHostFree(c->h_cloud_n); hipHostFree(c->h_RT);
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -585,11 +581,8 @@ static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, co
                       const TrackParams& tp) {
   fill_desc(c->h_desc, ref, curr, R, T);
   { int rc = wait_ready(c, ref); if (rc) return rc; rc = wait_ready(c, curr); if (rc) return rc; }
-  HIPCHECK(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PairDesc), hipMemcpyHostToDevice, c->stream));
-  launch_track(c->d_desc, tp, c->d_res, c->d_eval, 1, c->d_mail, pick_cluster(c, 1), c->stream);
+  launch_track_one(*c->h_desc, tp, c->h_res, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->stream);
   HIPCHECK(hipGetLastError());
-  if (tp.eval_only) HIPCHECK(hipMemcpyAsync(c->h_eval, c->d_eval, sizeof(EvalOut), hipMemcpyDeviceToHost, c->stream));
-  else HIPCHECK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(revo_pair_result), hipMemcpyDeviceToHost, c->stream));
   HIPCHECK(hipStreamSynchronize(c->stream));
   return REVO_OK;
 }
@@ -703,24 +696,21 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
   float inv[16];
   mat4_inverse(T_w_curr, inv);
   int nframes = 0;
+  VoteArgs va{};
   for (int fr = 0; fr < c->ts.n_frames_hist_voting && fr < (int)c->past.size() && fr < 3; ++fr) {
     float tf[16];
     mat4_mul(inv, c->past[fr].T_w, tf);
-    float* RT = c->h_RT + 12 * fr;
+    float* RT = va.RT[fr];
     for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 3; ++r) RT[cc * 3 + r] = tf[cc * 4 + r];
     RT[9] = tf[12]; RT[10] = tf[13]; RT[11] = tf[14];
-    c->h_cloud_pts[fr] = c->past[fr].d_pts;
-    c->h_cloud_n[fr] = c->past[fr].d_n;
+    va.pts[fr] = c->past[fr].d_pts;
+    va.n[fr] = c->past[fr].d_n;
     ++nframes;
   }
-  HIPCHECK(hipMemcpyAsync(c->d_RT, c->h_RT, sizeof(float) * 12 * nframes, hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(c->d_cloud_pts, c->h_cloud_pts, sizeof(void*) * nframes, hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(c->d_cloud_n, c->h_cloud_n, sizeof(void*) * nframes, hipMemcpyHostToDevice, c->stream));
   const int use_orig = (c->ps.use_edge_hist && hl > c->ps.pyr_max_lvl) ? 1 : 0;
-  launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, c->d_cloud_pts, c->d_cloud_n, c->d_RT, c->d_marks, c->d_hist8,
+  launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, va, c->d_marks, c->d_hist8, c->d_vote_done, c->h_hist8,
               use_orig, c->stream);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipMemcpyAsync(c->h_hist8, c->d_hist8, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHECK(hipStreamSynchronize(c->stream));
   const int* hist = c->h_hist8;
   const int* ov = c->h_hist8 + 4;
@@ -751,10 +741,10 @@ extern "C" int revo_tracker_add_old_pcl(revo_ctx* c, const revo_pyr* src, int lv
     HIPCHECK(hipMalloc((void**)&p.d_pts, sizeof(float4) * maxpix));
     HIPCHECK(hipMalloc((void**)&p.d_n, sizeof(int)));
   }
-  // the count stays on the device; the whole capacity of the level is copied (<= 300 KB at level 2)
-  HIPCHECK(hipMemcpyAsync(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, sizeof(float4) * (size_t)c->geom.lv[lvl].npix,
-                          hipMemcpyDeviceToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(p.d_n, src->fs->p.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  // the count stays on the device: one kernel copies the n valid points and n (stream ordered)
+  launch_copy_cloud(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, p.d_n, src->fs->p.npts + f * REVO_L + lvl,
+                    c->stream);
+  HIPCHECK(hipGetLastError());
   p.n = -1;
   memcpy(p.T_w, T_w, sizeof(float) * 16);
   p.ts = ts;
@@ -797,6 +787,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   b->cluster = pick_cluster(c, n_pairs);
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
+  HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
   for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false});
   HIPCHECK(hipHostMalloc((void**)&b->h_descs, sizeof(PairDesc) * n_pairs));
   HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
@@ -868,7 +859,7 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
-  launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, b->cluster, s);
+  launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
   HIPCHECK(hipGetLastError());
   return REVO_OK;
 }
@@ -905,7 +896,7 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
-    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, b->cluster, s);
+    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
     HIPCHECK(hipEventRecord(b->ev1, s));
     HIPCHECK(hipEventSynchronize(b->ev1));
     float ms = 0.f;

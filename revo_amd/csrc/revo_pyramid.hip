@@ -813,15 +813,17 @@ __global__ void __launch_bounds__(256) k_grad_table(PyrGeom g, FramePlanes pl, i
 // ---------------------------------------------------------------------------
 // a17: assessTrackingQuality's counting maps (tracker.cpp:138-176).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_vote_mark(const float4* const* cloud_pts, const int* const* cloud_n,
-                                                   const float* RT, float fx, float fy, float cx, float cy, int W,
-                                                   int H, int* marks) {
+// The relative poses and cloud pointers of the <= 3 past frames travel in the kernel-argument
+// segment: no H2D copies in front of the vote (the sequential path is latency-bound).
+__global__ void __launch_bounds__(256) k_vote_mark(VoteArgs a, float fx, float fy, float cx, float cy, int W, int H,
+                                                   int* marks) {
   const int c = blockIdx.y;
-  const int n = *cloud_n[c];
-  const float* R = RT + 12 * c;
+  const int n = *a.n[c];
+  const float* R = a.RT[c];
   const float* T = R + 9;
+  const float4* pts = a.pts[c];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const float4 p = cloud_pts[c][i];
+    const float4 p = pts[i];
     float q[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) q[r] = ((R[r] * p.x + R[3 + r] * p.y) + R[6 + r] * p.z) + T[r];
@@ -832,21 +834,44 @@ __global__ void __launch_bounds__(256) k_vote_mark(const float4* const* cloud_pt
   }
 }
 
-__global__ void __launch_bounds__(256) k_vote_hist(const int* marks, const uint8_t* edges, const float* depth, int npix,
-                                                   float dmin, float dmax, int* hist8) {
+// Counts, then leaves everything it used clean for the next vote: the marks it read go back to 0
+// and the last block to finish moves the 8 counters into pinned host memory and zeroes them (no
+// memset, no D2H copy on the stream).
+__global__ void __launch_bounds__(256) k_vote_hist(int* marks, const uint8_t* edges, const float* depth, int npix,
+                                                   float dmin, float dmax, int* hist8, unsigned* done, int* host_out) {
   __shared__ int s_h[8];
+  __shared__ bool s_last;
   if (threadIdx.x < 8) s_h[threadIdx.x] = 0;
   __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int m = marks[i];
+    if (m) marks[i] = 0;
     const float Z = depth[i];
     if (depth_ok(Z, dmin, dmax)) {
-      const int val = __popc(marks[i]);
+      const int val = __popc(m);
       atomicAdd(&s_h[val], 1);
       if (edges[i] > 0) atomicAdd(&s_h[4 + val], 1);
     }
   }
   __syncthreads();
   if (threadIdx.x < 8 && s_h[threadIdx.x]) atomicAdd(&hist8[threadIdx.x], s_h[threadIdx.x]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(done, 1u) == gridDim.x - 1);
+  __syncthreads();
+  if (s_last) {
+    if (threadIdx.x < 8) host_out[threadIdx.x] = atomicExch(&hist8[threadIdx.x], 0);
+    if (threadIdx.x == 0) *done = 0u;
+    __threadfence_system();
+  }
+}
+
+// mPastPcl.push_back(cloud) (tracker.cpp:219): the n valid points and the count, one launch
+__global__ void __launch_bounds__(256) k_copy_cloud(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                    int* __restrict__ dst_n, const int* __restrict__ src_n) {
+  const int n = *src_n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dst_n = n;
 }
 
 }  // namespace
@@ -930,16 +955,17 @@ void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstri
   hipLaunchKernelGGL(k_grad_table, dim3((g.lv[0].npix + 255) / 256, g.n_levels, count), dim3(256), 0, s, g, p, f0, fstride);
 }
 
-void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds,
-                 const float4* const* d_cloud_pts, const int* const* d_cloud_n, const float* d_RT, int* d_marks,
-                 int* d_hist8, int use_orig_edges, hipStream_t s) {
+void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds, const VoteArgs& va,
+                 int* d_marks, int* d_hist8, unsigned* d_done, int* h_out8, int use_orig_edges, hipStream_t s) {
+  // d_marks, d_hist8 and d_done are all-zero on entry (zeroed at allocation, left clean by k_vote_hist)
   const LevelGeom& lv = g.lv[lvl];
-  hipMemsetAsync(d_marks, 0, sizeof(int) * lv.npix, s);
-  hipMemsetAsync(d_hist8, 0, sizeof(int) * 8, s);
   if (n_clouds > 0)
-    hipLaunchKernelGGL(k_vote_mark, dim3(32, n_clouds), dim3(256), 0, s, d_cloud_pts, d_cloud_n, d_RT, lv.fx, lv.fy,
-                       lv.cx, lv.cy, lv.w, lv.h, d_marks);
+    hipLaunchKernelGGL(k_vote_mark, dim3(32, n_clouds), dim3(256), 0, s, va, lv.fx, lv.fy, lv.cx, lv.cy, lv.w, lv.h, d_marks);
   const uint8_t* edges = (use_orig_edges ? curr.edges_orig[lvl] : curr.edges[lvl]) + (size_t)curr_frame * lv.npix;
   hipLaunchKernelGGL(k_vote_hist, dim3(16), dim3(256), 0, s, d_marks, edges,
-                     curr.depth[lvl] + (size_t)curr_frame * lv.npix, lv.npix, g.depth_min, g.depth_max, d_hist8);
+                     curr.depth[lvl] + (size_t)curr_frame * lv.npix, lv.npix, g.depth_min, g.depth_max, d_hist8, d_done, h_out8);
+}
+
+void launch_copy_cloud(float4* dst, const float4* src, int* dst_n, const int* src_n, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_cloud, dim3(16), dim3(256), 0, s, dst, src, dst_n, src_n);
 }

@@ -476,9 +476,14 @@ __device__ __forceinline__ float cost_level(const f4v* preg, gf4p pts, int first
 
 // ---- the kernel ---------------------------------------------------------------
 #define TRACK_OCC __attribute__((amdgpu_waves_per_eu(TRACK_WAVES_PER_EU, TRACK_WAVES_PER_EU)))
-__global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDesc* __restrict__ descs, TrackParams prm,
-                                                         revo_pair_result* __restrict__ out, EvalOut* __restrict__ eval_out,
-                                                         u64* __restrict__ mail, int n_pairs, int cluster) {
+// ONE: the single pair of the sequential API arrives by value in the kernel-argument segment (no
+// H2D copy of the descriptor in front of the launch); otherwise descs[] lives in HBM (batches).
+// epoch_base: mailbox epochs keep counting across launches, so the mailbox is never re-zeroed.
+template <bool ONE>
+__global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDesc one, const PairDesc* __restrict__ descs,
+                                                                   TrackParams prm, revo_pair_result* __restrict__ out,
+                                                                   EvalOut* __restrict__ eval_out, u64* __restrict__ mail,
+                                                                   int n_pairs, int cluster, unsigned epoch_base) {
   __shared__ Ctrl s_ctrl;
   __shared__ W0State s;
   __shared__ float s_part[NWAVES][32];
@@ -490,12 +495,12 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
 #ifdef REVO_TRACK_SETPRIO
   __builtin_amdgcn_s_setprio(REVO_TRACK_SETPRIO);
 #endif
-  const PairDesc& d = descs[pair];
+  const PairDesc& d = ONE ? one : descs[pair];
   u64* mail_pair = mail + (size_t)pair * 2 * cluster * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stride = cluster * TRACK_THREADS;
   const int first = member * TRACK_THREADS + tid;
-  unsigned epoch = 0;
+  unsigned epoch = epoch_base;
   int cur_level = -1;
   f4v preg[TRACK_MAXP > 0 ? TRACK_MAXP : 1];
 #pragma unroll
@@ -832,15 +837,37 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
 
 int track_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_track, TRACK_THREADS, 0) != hipSuccess) nb = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_track<false>, TRACK_THREADS, 0) != hipSuccess) nb = 1;
   return nb < 1 ? 1 : nb;
 }
 
+// Mailbox granules carry {epoch, value}; a launch uses at most MAX_TOTAL_EVALS + a few epochs, so every
+// launch gets a fresh window of TRACK_EPOCH_WINDOW epochs and stale granules of earlier launches can
+// never match.  The mailbox is zeroed when it is allocated and when the 32-bit counter would wrap.
+#define TRACK_EPOCH_WINDOW 8192u
+static unsigned next_epoch_base(unsigned* epoch_io, unsigned long long* d_mail, size_t mail_bytes, hipStream_t s) {
+  if (*epoch_io > 0xffffffffu - 2 * TRACK_EPOCH_WINDOW) {
+    hipMemsetAsync(d_mail, 0, mail_bytes, s);
+    *epoch_io = 0;
+  }
+  const unsigned base = *epoch_io;
+  *epoch_io += TRACK_EPOCH_WINDOW;
+  return base;
+}
+
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval, int n_pairs,
-                  unsigned long long* d_mail, int cluster, hipStream_t s) {
-  // granules carry epochs that restart at 1 every launch: zero the mailbox first (stream ordered)
-  if (cluster > 1) hipMemsetAsync(d_mail, 0, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32, s);
+                  unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s) {
+  static_assert(MAX_TOTAL_EVALS + 64 < TRACK_EPOCH_WINDOW, "epoch window too small");
+  const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32, s);
   const int groups = (n_pairs + 7) / 8;
-  hipLaunchKernelGGL(k_track, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, d_descs, prm, d_out,
-                     d_eval, (u64*)d_mail, n_pairs, cluster);
+  hipLaunchKernelGGL(k_track<false>, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, PairDesc{}, d_descs, prm, d_out,
+                     d_eval, (u64*)d_mail, n_pairs, cluster, base);
+}
+
+// one pair, descriptor by value; out / eval_out may be device-visible pinned host memory
+void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
+                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s) {
+  const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * 2 * (size_t)cluster * 32, s);
+  hipLaunchKernelGGL(k_track<true>, dim3(8 * cluster), dim3(TRACK_THREADS), 0, s, desc, (const PairDesc*)nullptr, prm, out,
+                     eval_out, (u64*)d_mail, 1, cluster, base);
 }
