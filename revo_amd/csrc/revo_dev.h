@@ -26,14 +26,14 @@ struct LevelGeom {
   int tiles_x, tiles_y;
   int pix_base;        // sum of npix of finer levels
   int row_base;        // sum of h of finer levels
-  int col_base;        // sum of w of finer levels
+  int strip_base;      // number of 64-column strips of finer levels (compaction launch decode)
   int cc_base;         // sum of w*nchunk of finer levels
 };
 
 struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
-  int total_tiles, total_pix, total_rows, total_cols, total_cc;
+  int total_tiles, total_pix, total_rows, total_strips, total_cc;
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
   int use_edge_hist;

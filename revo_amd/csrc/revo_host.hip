@@ -177,10 +177,10 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     v.tile_base = tile; tile += v.tiles_x * v.tiles_y;
     v.pix_base = pix; pix += v.npix;
     v.row_base = row; row += v.h;
-    v.col_base = col; col += v.w;
+    v.strip_base = col; col += (v.w + 63) / 64;
     v.cc_base = cc; cc += v.w * v.nchunk;
   }
-  g->total_tiles = tile; g->total_pix = pix; g->total_rows = row; g->total_cols = col; g->total_cc = cc;
+  g->total_tiles = tile; g->total_pix = pix; g->total_rows = row; g->total_strips = col; g->total_cc = cc;
   return 0;
 }
 

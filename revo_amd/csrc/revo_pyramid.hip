@@ -449,31 +449,82 @@ __global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
 }
 
 // a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes edgesPyr and its clone
-// edgesOrigPyr (imgpyramidrgbd.cpp:185-186).  4 pixels per thread: the first hop of all four is
-// ONE coalesced 16-byte load of the parents the NMS kernel wrote for this group; after k_ccl_flag
-// the second hop lands on the global root.
-__global__ void __launch_bounds__(256) k_ccl_out(PyrGeom g, FramePlanes pl) {
+// edgesOrigPyr (imgpyramidrgbd.cpp:185-186).  One block per NMS tile, 4 pixels per thread (the
+// mapping of k_canny_nms).  All candidates of a tile-local component share one tile root, and after
+// k_ccl_flag a tile root points straight at its global root: so only the tile's ROOTS (a handful)
+// chase pointers -- two batched loads each -- and leave their verdict in LDS; every other candidate
+// reads the verdict of its tile root from LDS.  (Before: every candidate pixel chased two dependent
+// global loads on its own.)  A parent that path halving moved out of the tile, or onto a non-root,
+// takes the global walk.
+__global__ void __launch_bounds__(NMS_THREADS) k_ccl_out(PyrGeom g, FramePlanes pl) {
+  __shared__ uint32_t s_verdict[NMS_TILE_H * NMS_TILE_W / 4];  // bytes: 0xff unknown, 0 weak-only, 1 holds a strong pixel
   const int f = g.frame0 + blockIdx.z;
-  const int l = blockIdx.y;
+  const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
   const LevelGeom& lv = g.lv[l];
-  const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (p0 >= lv.npix) return;
+  const int t = blockIdx.x - lv.tile_base;
+  const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
+  const int w = lv.w, h = lv.h;
+  const int tid = threadIdx.x;
+  uint8_t* verdict = reinterpret_cast<uint8_t*>(s_verdict);
   const uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
-  const uint32_t m = *reinterpret_cast<const uint32_t*>(nms + p0);
-  uint32_t o = 0;
-  if (m & 0x03030303u) {
-    const int* L = pl.scratch[l] + (size_t)f * lv.npix;
-    const int4 lab = *reinterpret_cast<const int4*>(L + p0);
-    const int tl[4] = {lab.x, lab.y, lab.z, lab.w};
+  const int* L = pl.scratch[l] + (size_t)f * lv.npix;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (((m >> (8 * k)) & 3u) == 0) continue;
-      const int r = uf_find_final(L, tl[k]);
-      if (nms[r] & 4) o |= 0xffu << (8 * k);
-    }
+  for (int ps = 0; ps < NMS_PASSES; ++ps) s_verdict[ps * NMS_THREADS + tid] = 0xffffffffu;
+  uint32_t m[NMS_PASSES];
+  int p0[NMS_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
+    const bool inside = (x0 + lx0 < w) && (y0 + ly < h);  // w is a multiple of 4: a group is inside or outside as a whole
+    p0[ps] = (y0 + ly) * w + x0 + lx0;
+    m[ps] = inside ? *reinterpret_cast<const uint32_t*>(nms + p0[ps]) : 0u;
   }
-  *reinterpret_cast<uint32_t*>(pl.edges[l] + (size_t)f * lv.npix + p0) = o;
-  *reinterpret_cast<uint32_t*>(pl.edges_orig[l] + (size_t)f * lv.npix + p0) = o;
+  __syncthreads();
+  // tile roots: global root, then its strong bit (both hops batched over the 4 pixels of the thread)
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    if ((m[ps] & 0x08080808u) == 0) continue;
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
+    int r[4];
+    uint8_t fl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = ((m[ps] >> (8 * k)) & 8u) ? L[p0[ps] + k] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fl[k] = r[k] >= 0 ? nms[r[k]] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (r[k] >= 0) verdict[ly * NMS_TILE_W + lx0 + k] = (fl[k] & 4u) ? 1 : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps) {
+    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
+    if (!((x0 + lx0 < w) && (y0 + ly < h))) continue;
+    uint32_t o = 0;
+    if (m[ps] & 0x03030303u) {
+      const int4 lab = *reinterpret_cast<const int4*>(L + p0[ps]);
+      const int tl[4] = {lab.x, lab.y, lab.z, lab.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (m[ps] >> (8 * k)) & 0xffu;
+        if ((b & 3u) == 0) continue;
+        int v;
+        if (b & 8u) {
+          v = verdict[ly * NMS_TILE_W + lx0 + k];  // a tile root: its own verdict
+        } else {
+          const int py = tl[k] / w - y0, px = tl[k] % w - x0;
+          v = (py >= 0 && py < NMS_TILE_H && px >= 0 && px < NMS_TILE_W) ? verdict[py * NMS_TILE_W + px] : 0xff;
+        }
+        if (v == 0xff) {  // parent outside the tile or not a tile root (moved by path halving): walk
+          const int r = uf_find_final(L, tl[k]);
+          v = (nms[r] & 4) ? 1 : 0;
+        }
+        if (v) o |= 0xffu << (8 * k);
+      }
+    }
+    *reinterpret_cast<uint32_t*>(pl.edges[l] + (size_t)f * lv.npix + p0[ps]) = o;
+    *reinterpret_cast<uint32_t*>(pl.edges_orig[l] + (size_t)f * lv.npix + p0[ps]) = o;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -567,41 +618,105 @@ __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
   return isfinite(Z) && Z > dmin && Z < dmax;  // imgpyramidrgbd.cpp:208
 }
 
+// One block = a strip of 64 columns x all row-chunks of the level (thread = column x chunk lane,
+// a wave = 64 adjacent columns of one chunk, so edge / depth rows are read 64 B at a time).  The
+// strip's slots (x-major, chunk-minor: the order of the scan) are one contiguous range of the chunk /
+// mask arrays and its points one contiguous range of the list, so both go through LDS and reach
+// HBM coalesced.  (Thread-per-slot with direct stores measured 10x write amplification on the slot
+// arrays and 3x on the points: WRITE_SIZE 45 MB and 68 MB for 5 MB and 23 MB of data.)
+#define CW_COLS 64
+#define CW_LANES 16                    // chunk lanes per block (1024 threads); levels with more chunks loop
+#define CW_MAXCHUNK 32                 // height <= 1024
+#define CW_STAGE 4096                  // points staged in LDS per strip (64 KB); denser strips store directly
 template <bool WRITE>
-__global__ void __launch_bounds__(256) k_compact_walk(PyrGeom g, FramePlanes pl) {
+__global__ void __launch_bounds__(CW_COLS * CW_LANES) k_compact_walk(PyrGeom g, FramePlanes pl) {
+  __shared__ int s_cnt[CW_COLS * CW_MAXCHUNK];        // count pass: counts; write pass: offsets
+  __shared__ unsigned s_mask[CW_COLS * CW_MAXCHUNK];
+  __shared__ float4 s_pts[WRITE ? CW_STAGE : 1];
   const int f = g.frame0 + blockIdx.z;
-  const int l = blockIdx.y;  // block-uniform level
+  const int l = level_of(g, blockIdx.x, &LevelGeom::strip_base);
   const LevelGeom& lv = g.lv[l];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= lv.w * lv.nchunk) return;
-  const int x = i % lv.w, c = i / lv.w;  // adjacent threads walk adjacent columns
-  const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
+  const int strip = blockIdx.x - lv.strip_base;
+  const int tid = threadIdx.x, xl = tid & (CW_COLS - 1), cl = tid / CW_COLS;
+  const int x = strip * CW_COLS + xl;
+  const int ncols = min(CW_COLS, lv.w - strip * CW_COLS);
+  const int nslots = ncols * lv.nchunk;
+  const size_t slot0 = (size_t)f * lv.w * lv.nchunk + (size_t)strip * CW_COLS * lv.nchunk;  // first slot of the strip
   const float* depth = pl.depth[l] + (size_t)f * lv.npix;
-  const size_t slot_i = (size_t)f * lv.w * lv.nchunk + (size_t)x * lv.nchunk + c;  // column-major chunk order
   if (!WRITE) {
     // count: the depth plane is only touched where there is an edge (~8 % of the pixels); the
     // validity of the 32 rows is kept as a bit mask for the write pass
     const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
-    unsigned em = 0;
+    if (x < lv.w) {
+      for (int c = cl; c < lv.nchunk; c += CW_LANES) {
+        const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
+        unsigned em = 0;
 #pragma unroll 8
-    for (int y = yb; y < ye; ++y) em |= (edges[(size_t)y * lv.w + x] ? 1u : 0u) << (y - yb);
-    unsigned vm = 0;
-    for (unsigned m = em; m; m &= m - 1) {
-      const int b = __ffs(m) - 1;
-      const float Z = depth[(size_t)(yb + b) * lv.w + x];
-      if (depth_ok(Z, g.depth_min, g.depth_max)) vm |= 1u << b;
+        for (int y = yb; y < ye; ++y) em |= (edges[(size_t)y * lv.w + x] ? 1u : 0u) << (y - yb);
+        // four set bits per trip: the depth loads of a trip are independent, so a column with k edge
+        // pixels costs ceil(k/4) memory round trips instead of k
+        unsigned vm = 0;
+        for (unsigned m = em; m;) {
+          int b[4];
+          float Z[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            b[j] = m ? __ffs(m) - 1 : -1;
+            m &= m - 1;  // 0 stays 0
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Z[j] = b[j] >= 0 ? depth[(size_t)(yb + b[j]) * lv.w + x] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (b[j] >= 0 && depth_ok(Z[j], g.depth_min, g.depth_max)) vm |= 1u << b[j];
+        }
+        s_mask[xl * lv.nchunk + c] = vm;
+        s_cnt[xl * lv.nchunk + c] = __popc(vm);
+      }
     }
-    pl.cmask[l][slot_i] = vm;
-    pl.chunk[l][slot_i] = __popc(vm);
+    __syncthreads();
+    for (int i = tid; i < nslots; i += CW_COLS * CW_LANES) {
+      pl.cmask[l][slot0 + i] = s_mask[i];
+      pl.chunk[l][slot0 + i] = s_cnt[i];
+    }
   } else {
-    int o = pl.chunk[l][slot_i];
+    for (int i = tid; i < nslots; i += CW_COLS * CW_LANES) {
+      s_mask[i] = pl.cmask[l][slot0 + i];
+      s_cnt[i] = pl.chunk[l][slot0 + i];
+    }
+    __syncthreads();
+    const int base = s_cnt[0];
+    const int total = s_cnt[nslots - 1] + __popc(s_mask[nslots - 1]) - base;
+    const bool staged = total <= CW_STAGE;
     float4* out = pl.pts[l] + (size_t)f * lv.npix;
-    for (unsigned m = pl.cmask[l][slot_i]; m; m &= m - 1) {
-      const int y = yb + __ffs(m) - 1;
-      const float Z = depth[(size_t)y * lv.w + x];
-      const float X = __fdiv_rn(Z * ((float)x - lv.cx), lv.fx);
-      const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
-      out[o++] = make_float4(X, Y, Z, 1.0f);
+    if (x < lv.w) {
+      for (int c = cl; c < lv.nchunk; c += CW_LANES) {
+        const int yb = c * lv.chunk_rows;
+        int o = s_cnt[xl * lv.nchunk + c] - (staged ? base : 0);
+        float4* dst = staged ? s_pts : out;
+        for (unsigned m = s_mask[xl * lv.nchunk + c]; m;) {  // four points per trip (independent depth loads)
+          int y[4];
+          float Z[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            y[j] = m ? yb + __ffs(m) - 1 : -1;
+            m &= m - 1;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Z[j] = y[j] >= 0 ? depth[(size_t)y[j] * lv.w + x] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (y[j] < 0) continue;
+            const float X = __fdiv_rn(Z[j] * ((float)x - lv.cx), lv.fx);
+            const float Y = __fdiv_rn(Z[j] * ((float)y[j] - lv.cy), lv.fy);
+            dst[o++] = make_float4(X, Y, Z[j], 1.0f);
+          }
+        }
+      }
+    }
+    if (staged) {
+      __syncthreads();
+      for (int i = tid; i < total; i += CW_COLS * CW_LANES) out[base + i] = s_pts[i];
     }
   }
 }
@@ -901,7 +1016,7 @@ void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid((g.lv[0].npix / 16 + 255) / 256, g.n_levels, B);
   hipLaunchKernelGGL(k_ccl_border, dim3(g.total_tiles, 1, B), dim3(64 + 2 * NMS_TILE_H), 0, s, g, p);
   hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
-  hipLaunchKernelGGL(k_ccl_out, dim3((g.lv[0].npix / 4 + 255) / 256, g.n_levels, B), dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_ccl_out, dim3(g.total_tiles, 1, B), dim3(NMS_THREADS), 0, s, g, p);
 }
 
 void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
@@ -915,10 +1030,10 @@ void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  dim3 grid((g.lv[0].w * g.lv[0].nchunk + 255) / 256, g.n_levels, B);
-  hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(256), 0, s, g, p);
+  dim3 grid(g.total_strips, 1, B);
+  hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels, 1, B), dim3(1024), 0, s, g, p);
-  hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
 }
 
 void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s) {
