@@ -492,9 +492,6 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   const int pair = (b / (8 * cluster)) * 8 + (b % 8);
   const int member = (b / 8) % cluster;
   if (pair >= n_pairs) return;
-#ifdef REVO_TRACK_SETPRIO
-  __builtin_amdgcn_s_setprio(REVO_TRACK_SETPRIO);
-#endif
   const PairDesc& d = ONE ? one : descs[pair];
   u64* mail_pair = mail + (size_t)pair * 2 * cluster * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -142,6 +142,21 @@ def test_pyramid_edge_cases_320(api, ro):
     assert not np.array_equal(op.read(PLANE_EDGES, 1), op.read(PLANE_EDGES_ORIG, 1))
 
 
+def test_dense_edges_640_take_the_unstaged_compaction_path(api, ro):
+    """Dense noise at full size: a 64-column strip of the ordered compaction then holds more points
+    than its LDS staging area (4096), so the direct-store path of k_compact_walk runs; the tile-local
+    union-find sees huge components.  Bit-exact like everything else."""
+    s = tum_settings(3)
+    name, bgr, depth = [c for c in _edge_cases(s) if c[0] == "noise"][0]
+    cam = api.CameraPyr(s)
+    gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+    op = ro.Pyramid(s, bgr, depth)
+    gp.makeKeyframe()
+    op.makeKeyframe()
+    compare_pyramid("dense640", gp, op, s, True)
+    assert gp.return3DEdges(0).shape[0] > 10 * 4096  # > 4096 per strip on average (10 strips)
+
+
 def test_u16_depth_entry_point(api, ro):
     s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
     bgr, depth = synth.make_pair(1, s)["ref"]
