@@ -1234,3 +1234,57 @@ int ro_vo_push(ro_vo* v, const uint8_t* bgr, size_t bgr_stride, const float* dep
   v->prev = curr;
   return new_kf;
 }
+
+/* ======================================================================== */
+/* Multi-threaded CPU baseline (bench.py "cpu_baseline_all_cores")           */
+/* One frame-pair per thread at a time: 2 pyramids + makeKeyframe +          */
+/* trackFrames from identity, exactly the per-pair work of the GPU batch.    */
+/* Plain pthreads so that the number is not limited by the Python GIL.       */
+/* ======================================================================== */
+#include <pthread.h>
+typedef struct {
+  const revo_pyr_settings* ps; const revo_opt_settings* os; const revo_tracker_settings* ts;
+  const uint8_t* bgr; const float* depth; /* [2*n_pairs] frames: ref, curr, ref, curr, ... */
+  int n_pairs, first; double seconds; long done;
+} ro_mt_job;
+
+static void* ro_mt_worker(void* arg) {
+  ro_mt_job* j = (ro_mt_job*)arg;
+  const int w = j->ps->width, h = j->ps->height;
+  const size_t fb = (size_t)w * h * 3, fd = (size_t)w * h;
+  ro_tracker* t = ro_tracker_create(j->ps, j->os, j->ts);
+  const double t0 = now_s();
+  int i = j->first % j->n_pairs;
+  while (now_s() - t0 < j->seconds) {
+    ro_pyramid* ref = ro_pyramid_create(j->ps, j->bgr + (size_t)(2 * i) * fb, (size_t)w * 3, j->depth + (size_t)(2 * i) * fd, (size_t)w * 4, 0.0);
+    ro_pyramid* cur = ro_pyramid_create(j->ps, j->bgr + (size_t)(2 * i + 1) * fb, (size_t)w * 3, j->depth + (size_t)(2 * i + 1) * fd, (size_t)w * 4, 0.0);
+    ro_pyramid_make_keyframe(ref);
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0}, err = 0.f;
+    int flags = 0;
+    ro_tracker_track_frames(t, ref, cur, R, T, &err, NULL, NULL, &flags);
+    ro_pyramid_destroy(ref);
+    ro_pyramid_destroy(cur);
+    j->done += 1;
+    i = (i + 1) % j->n_pairs;
+  }
+  ro_tracker_destroy(t);
+  return NULL;
+}
+
+long ro_bench_pairs_mt(const revo_pyr_settings* ps, const revo_opt_settings* os, const revo_tracker_settings* ts,
+                       const uint8_t* bgr, const float* depth, int n_pairs, int n_threads, double seconds,
+                       double* elapsed_out) {
+  if (n_threads < 1) n_threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  ro_mt_job* jobs = (ro_mt_job*)calloc((size_t)n_threads, sizeof(ro_mt_job));
+  const double t0 = now_s();
+  for (int k = 0; k < n_threads; ++k) {
+    jobs[k] = (ro_mt_job){ps, os, ts, bgr, depth, n_pairs, k, seconds, 0};
+    pthread_create(&th[k], NULL, ro_mt_worker, &jobs[k]);
+  }
+  long total = 0;
+  for (int k = 0; k < n_threads; ++k) { pthread_join(th[k], NULL); total += jobs[k].done; }
+  if (elapsed_out) *elapsed_out = now_s() - t0;
+  free(th); free(jobs);
+  return total;
+}

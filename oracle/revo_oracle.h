@@ -134,6 +134,13 @@ int ro_vo_num_keyframes(const ro_vo* v);
  * cumulative seconds spent in (pyramid build, makeKeyframe, tracking+vote). */
 void ro_vo_times(const ro_vo* v, double out3[3]);
 
+/* bench.py's all-core CPU baseline: n_threads pthreads, one frame-pair per thread at a time (2 pyramids +
+ * makeKeyframe + trackFrames from identity) for `seconds`; frames are packed [ref0,curr0,ref1,...].  Returns
+ * the pairs completed. */
+long ro_bench_pairs_mt(const revo_pyr_settings* ps, const revo_opt_settings* os, const revo_tracker_settings* ts,
+                       const uint8_t* bgr, const float* depth, int n_pairs, int n_threads, double seconds,
+                       double* elapsed_out);
+
 #ifdef __cplusplus
 }
 #endif

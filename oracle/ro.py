@@ -101,6 +101,10 @@ def lib():
         L.ro_edges3d.argtypes = [u8p, f32p, C.c_int, C.c_int] + [C.c_float] * 6 + [f32p]
         L.ro_u16_to_depth.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, C.c_int, C.c_int, C.c_double, f32p]
         L.ro_set_accum_double.argtypes = [C.c_int]
+        L.ro_bench_pairs_mt.restype = C.c_long
+        L.ro_bench_pairs_mt.argtypes = [C.POINTER(ImgPyramidSettings), C.POINTER(OptimizerSettings),
+                                        C.POINTER(TrackerSettings), u8p, f32p, C.c_int, C.c_int, C.c_double,
+                                        C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -383,3 +387,14 @@ class VO:
         out = (C.c_double * 3)()
         lib().ro_vo_times(self.h, out)
         return tuple(out)
+
+
+def bench_pairs_mt(ps, bgr_frames, depth_frames, n_threads, seconds, os_=None, ts=None):
+    """All-core CPU baseline (native pthreads): frames packed [ref0, curr0, ref1, ...] -> (pairs done, elapsed s)."""
+    bgr = np.ascontiguousarray(bgr_frames, np.uint8)
+    dep = np.ascontiguousarray(depth_frames, np.float32)
+    el = C.c_double()
+    os_, ts = os_ or OptimizerSettings(), ts or TrackerSettings()
+    n = lib().ro_bench_pairs_mt(C.byref(ps), C.byref(os_), C.byref(ts), _p(bgr, u8p), _p(dep, f32p), bgr.shape[0] // 2,
+                                int(n_threads), float(seconds), C.byref(el))
+    return int(n), el.value
