@@ -90,16 +90,30 @@ def test_pyramid_and_keyframe_bit_exact_640(api, ro, pair640):
         assert 15000 < n0 < 40000  # the design's edge budget (iowrapperRGBD.cpp:121-122)
 
 
-@pytest.mark.parametrize("levels,hist", [(4, (20, 10, 5, 0, 0, 0)), (2, (20, 10, 0, 0, 0, 0))])
+@pytest.mark.parametrize("levels,hist", [(4, (20, 10, 5, 0, 0, 0)), (2, (20, 10, 0, 0, 0, 0)), (1, (20, 0, 0, 0, 0, 0)),
+                                         (6, (20, 10, 5, 0, 0, 0))])
 def test_pyramid_other_level_counts(api, ro, levels, hist):
-    s = ImgPyramidSettings(pyr_min_lvl=levels - 1, hist_patch=hist)
-    bgr, depth = synth.make_pair(5, s)["ref"]
+    """1 level (no pyramid at all) up to REVO_MAX_LEVELS = 6 (at 1280x960: 40x30 at the top; every level must
+    hold a multiple of 16 pixels, which a 6-level 640x480 pyramid does not): pyramid + keyframe bit-exact and
+    the coarse-to-fine tracker within tolerance."""
+    s = (ImgPyramidSettings.scaled(1280, 960, 6, hist_patch=hist) if levels == 6
+         else ImgPyramidSettings(pyr_min_lvl=levels - 1, hist_patch=hist))
+    pair = synth.make_pair(5, s, max_t=0.01, max_rot_deg=0.3) if levels == 1 else synth.make_pair(5, s)
+    bgr, depth = pair["ref"]
     cam = api.CameraPyr(s)
     gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
     op = ro.Pyramid(s, bgr, depth)
     gp.makeKeyframe()
     op.makeKeyframe()
     compare_pyramid("lv%d" % levels, gp, op, s, True)
+    ts = TrackerSettings(histogram_level=min(2, levels - 1))
+    gt = api.TrackerNew(ts, s, cam)
+    ot = ro.Tracker(s, OptimizerSettings(), ts)
+    gc = api.ImgPyramidRGBD(s, cam, *pair["curr"])
+    oc = ro.Pyramid(s, *pair["curr"])
+    st_g, R_g, T_g, err_g = gt.trackFrames(np.eye(3), np.zeros(3), gp, gc)
+    r_o = ot.trackFrames(op, oc, np.eye(3), np.zeros(3))
+    assert rot_angle(R_g, r_o["R"]) < ROT_TOL and np.linalg.norm(T_g - r_o["T"]) < TRANS_TOL, (levels, T_g, r_o["T"])
 
 
 def _edge_cases(s):
