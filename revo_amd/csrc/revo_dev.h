@@ -105,7 +105,9 @@ struct EvalOut {
 #define NMS_ROWS_PER_PASS (NMS_THREADS / 16)
 #define NMS_PASSES (NMS_TILE_H / NMS_ROWS_PER_PASS)
 #define TRACK_THREADS 512
+#ifndef TRACK_MAX_CLUSTER
 #define TRACK_MAX_CLUSTER 8
+#endif
 
 // ---- launchers (defined in the kernel translation units) -------------------
 void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,

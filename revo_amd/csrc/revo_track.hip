@@ -294,15 +294,23 @@ __device__ __forceinline__ bool cluster_allgather(u64* __restrict__ mail_pair, i
     bool all = true;
     tot = 0.0;
     if (lane < 32) {
-      for (int j = 0; j < cluster; ++j) {
-        const u64 g = __hip_atomic_load(&slot[j * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        all = all && ((unsigned)(g >> 32) == epoch);
-        tot += (double)__uint_as_float((unsigned)g);  // fixed order j = 0..cluster-1: same bits in every member
+      // all member granules in flight at once (a rolled loop over `cluster` waited for every load before
+      // issuing the next: 8 serial L2 round trips per poll, the exchange cost grew linearly with the cluster)
+      u64 g[TRACK_MAX_CLUSTER];
+#pragma unroll
+      for (int j = 0; j < TRACK_MAX_CLUSTER; ++j)
+        g[j] = (j < cluster) ? __hip_atomic_load(&slot[j * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+      for (int j = 0; j < TRACK_MAX_CLUSTER; ++j) {
+        if (j < cluster) {
+          all = all && ((unsigned)(g[j] >> 32) == epoch);
+          tot += (double)__uint_as_float((unsigned)g[j]);  // fixed order j = 0..cluster-1: same bits in every member
+        }
       }
     }
     if (__all(all)) break;
     if (spins > SPIN_LIMIT) return false;
-    __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_s_sleep(1);
   }
   *tot_out = tot;
   return true;
