@@ -140,15 +140,30 @@ __device__ __forceinline__ int uf_find_halving(int* L, int x) {
   }
   return x;
 }
+// The two root walks run in lockstep: the two loads of a step are independent, so a union costs
+// max(depth_a, depth_b) round trips instead of depth_a + depth_b.
 __device__ __forceinline__ void uf_unite_global(int* L, int a, int b) {
+  int pa = uf_load(L, a), pb = uf_load(L, b);
   for (;;) {
-    a = uf_find_halving(L, a);
-    b = uf_find_halving(L, b);
+    while (pa != a || pb != b) {
+      const int ga = (pa != a) ? uf_load(L, pa) : pa;
+      const int gb = (pb != b) ? uf_load(L, pb) : pb;
+      if (pa != a) {
+        if (ga != pa) atomicMin(&L[a], ga);  // path halving
+        a = pa; pa = ga;
+      }
+      if (pb != b) {
+        if (gb != pb) atomicMin(&L[b], gb);
+        b = pb; pb = gb;
+      }
+    }
     if (a == b) return;
-    if (a > b) { const int t = a; a = b; b = t; }
+    if (a > b) { const int t = a; a = b; b = t; }  // a < b: hang b under a
     const int old = atomicMin(&L[b], a);
     if (old == b) return;
-    b = old;
+    b = old;  // b was re-parented meanwhile: keep that link by uniting with it too
+    pa = uf_load(L, a);
+    pb = uf_load(L, b);
   }
 }
 // After a kernel boundary the forest is final: plain (cacheable) loads.
@@ -415,13 +430,20 @@ __global__ void __launch_bounds__(64 + 2 * NMS_TILE_H) k_ccl_border(PyrGeom g, F
   const int p = y * w + x;
   if ((nmsp[p] & 3) == 0) return;
   int* L = pl.scratch[l] + (size_t)f * lv.npix;
-  // neighbours that live in another tile
-  if (lx == 0 && x > 0 && (nmsp[p - 1] & 3)) uf_unite_global(L, p, p - 1);
-  if (y > 0) {
-    if ((lx == 0 || ly == 0) && x > 0 && (nmsp[p - w - 1] & 3)) uf_unite_global(L, p, p - w - 1);
-    if (ly == 0 && (nmsp[p - w] & 3)) uf_unite_global(L, p, p - w);
-    if ((lx == NMS_TILE_W - 1 || ly == 0) && x < w - 1 && (nmsp[p - w + 1] & 3)) uf_unite_global(L, p, p - w + 1);
-  }
+  // neighbours that live in another tile: the four map bytes are fetched together (they were four
+  // dependent round trips behind short-circuit conditions), then the unions run
+  const bool want_w = lx == 0 && x > 0;
+  const bool want_nw = y > 0 && (lx == 0 || ly == 0) && x > 0;
+  const bool want_n = y > 0 && ly == 0;
+  const bool want_ne = y > 0 && (lx == NMS_TILE_W - 1 || ly == 0) && x < w - 1;
+  const uint8_t b_w = want_w ? nmsp[p - 1] : (uint8_t)0;
+  const uint8_t b_nw = want_nw ? nmsp[p - w - 1] : (uint8_t)0;
+  const uint8_t b_n = want_n ? nmsp[p - w] : (uint8_t)0;
+  const uint8_t b_ne = want_ne ? nmsp[p - w + 1] : (uint8_t)0;
+  if (b_w & 3) uf_unite_global(L, p, p - 1);
+  if (b_nw & 3) uf_unite_global(L, p, p - w - 1);
+  if (b_n & 3) uf_unite_global(L, p, p - w);
+  if (b_ne & 3) uf_unite_global(L, p, p - w + 1);
 }
 
 // a5 (2/3): only TILE ROOTS (bit 3) work here: each is re-pointed straight at its global
@@ -479,16 +501,25 @@ __global__ void __launch_bounds__(NMS_THREADS) k_ccl_out(PyrGeom g, FramePlanes 
     p0[ps] = (y0 + ly) * w + x0 + lx0;
     m[ps] = inside ? *reinterpret_cast<const uint32_t*>(nms + p0[ps]) : 0u;
   }
+  // the parents of this thread's 4 pixels (one coalesced int4, only where there is a candidate): for a
+  // tile root that IS its global root after k_ccl_flag, for the others their tile root -- fetched once,
+  // before the root phase, so that a block spends 3 dependent round trips (map, parents, root's map
+  // byte) instead of 5
+  int4 lab[NMS_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < NMS_PASSES; ++ps)
+    lab[ps] = (m[ps] & 0x03030303u) ? *reinterpret_cast<const int4*>(L + p0[ps]) : make_int4(-1, -1, -1, -1);
   __syncthreads();
-  // tile roots: global root, then its strong bit (both hops batched over the 4 pixels of the thread)
+  // tile roots: the strong bit of their global root (batched over the 4 pixels of the thread)
 #pragma unroll
   for (int ps = 0; ps < NMS_PASSES; ++ps) {
     if ((m[ps] & 0x08080808u) == 0) continue;
     const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
+    const int tl[4] = {lab[ps].x, lab[ps].y, lab[ps].z, lab[ps].w};
     int r[4];
     uint8_t fl[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = ((m[ps] >> (8 * k)) & 8u) ? L[p0[ps] + k] : -1;
+    for (int k = 0; k < 4; ++k) r[k] = ((m[ps] >> (8 * k)) & 8u) ? tl[k] : -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) fl[k] = r[k] >= 0 ? nms[r[k]] : (uint8_t)0;
 #pragma unroll
@@ -502,8 +533,7 @@ __global__ void __launch_bounds__(NMS_THREADS) k_ccl_out(PyrGeom g, FramePlanes 
     if (!((x0 + lx0 < w) && (y0 + ly < h))) continue;
     uint32_t o = 0;
     if (m[ps] & 0x03030303u) {
-      const int4 lab = *reinterpret_cast<const int4*>(L + p0[ps]);
-      const int tl[4] = {lab.x, lab.y, lab.z, lab.w};
+      const int tl[4] = {lab[ps].x, lab[ps].y, lab[ps].z, lab[ps].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint32_t b = (m[ps] >> (8 * k)) & 0xffu;
