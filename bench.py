@@ -217,6 +217,24 @@ def main():
             traffic = float(json.load(open(pmc_file))["k_track"]["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
+    # on-box streaming ceiling next to the vendor peak: a 1 GiB device-to-device copy
+    copy_gbs = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except RuntimeError:
+            copy_gbs = None
     out = {
         "metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference",
         "value": world * a.pairs * a.steps / elapsed,
@@ -243,6 +261,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
             "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track,
+            "measured_copy_gbs": copy_gbs,  # on-box device-to-device copy ceiling (read + write bytes), for context
         },
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},
         "pose_error_vs_ground_truth": {"rot_rad_median": rot_med, "trans_m_median": tr_med},
@@ -278,10 +297,12 @@ def main():
             t_pyr, t_kf, t_trk = ovo.times()  # seconds in: pyramid builds, makeKeyframe, tracking + vote
             # the reference builds pyramids on its IO thread (system.cpp:96): 2-core pipelined rate (derived)
             cpu_seq_2core = min(n, 40) / max(t_pyr, t_kf + t_trk)
+            cpu_trk_only = min(n, 40) / t_trk
         out["single_stream"] = {"frames_per_s": n / dt_seq, "frames": n, "keyframes": drv.nKeyFrames,
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
                                 "cpu_oracle_frames_per_s_1core": cpu_seq,
                                 "cpu_oracle_frames_per_s_2core_pipelined_derived": cpu_seq_2core if cpu_seq else None,
+                                "cpu_oracle_tracker_only_frames_per_s_1core": cpu_trk_only if cpu_seq else None,
                                 "speedup_vs_cpu_oracle_2core_pipelined": (n / dt_seq / cpu_seq_2core) if cpu_seq else None,
                                 "speedup_vs_cpu_oracle": (n / dt_seq / cpu_seq) if cpu_seq else None,
                                 "note": "sequential REVO::start sequencing (revo_vo_*) via the host-buffer C ABI on a seeded synthetic "
