@@ -129,8 +129,6 @@ struct revo_batch {
   int cluster;
   hipStream_t stream;
   hipEvent_t ev0, ev1, ev_upload;
-  hipStream_t stream2;      // second half of a split build
-  hipEvent_t ev_fork, ev_join;
 };
 
 // ---------------------------------------------------------------- geometry --
@@ -782,9 +780,6 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
   HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
-  HIPCHECK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
-  HIPCHECK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-  HIPCHECK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   b->cluster = pick_cluster(c, n_pairs);
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
@@ -802,7 +797,6 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   hipStreamSynchronize(b->stream);
   hipHostFree(b->h_descs); hipFree(b->d_descs); hipFree(b->d_mail);
   hipEventDestroy(b->ev0); hipEventDestroy(b->ev1); hipEventDestroy(b->ev_upload);
-  hipEventDestroy(b->ev_fork); hipEventDestroy(b->ev_join); hipStreamDestroy(b->stream2);
   hipStreamDestroy(b->stream);
   frameset_destroy(b->fs);
   revo_ctx* c = b->ctx;
@@ -814,25 +808,10 @@ extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float
   if (!b || !d_bgr || !d_depth) return fail(REVO_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-  // The build is a chain of ~18 short, latency-bound kernels: the two halves of the batch run
-  // on two streams (fork/join by events) so those kernels overlap each other.
-  // (measured r01: 0.895 -> 0.854 ms for the build stage, but no gain once the tracker of the previous
-  // step overlaps: the build kernels are throughput-limited, not latency-idle -- off by default)
-  const int half_pairs = (b->n_pairs >= 8 && getenv("REVO_SPLIT_BUILD")) ? b->n_pairs / 2 : 0;
-  if (half_pairs > 0) {
-    HIPCHECK(hipEventRecord(b->ev_fork, s));
-    HIPCHECK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
-    const int fa = 2 * half_pairs, fb = 2 * b->n_pairs - fa;
-    enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, 0, fa);
-    launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, half_pairs, s);
-    enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, b->stream2, fa, fb);
-    launch_keyframe(b->ctx->geom, b->fs->p, fa, 2, b->n_pairs - half_pairs, b->stream2);
-    HIPCHECK(hipEventRecord(b->ev_join, b->stream2));
-    HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
-  } else {
-    enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s);
-    launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
-  }
+  // (Splitting the batch over two streams was measured twice -- before and after the tracker's register
+  // diet -- at no gain once a tracker overlaps: the build kernels are throughput-limited.)
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s);
+  launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
   HIPCHECK(hipGetLastError());
   for (auto& v : b->views) v.table_built = false;
   return REVO_OK;
