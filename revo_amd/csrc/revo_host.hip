@@ -296,6 +296,7 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
 }
 
 // ------------------------------------------------------------------ context --
+static void ctx_free(revo_ctx* c);
 extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const revo_opt_settings* opt,
                                const revo_tracker_settings* trk, revo_ctx** out) {
   if (!pyr || !out) return fail(REVO_ERR_INVALID_ARG, "null argument");
@@ -312,6 +313,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   std::string why;
   if (build_geom(c->ps, &c->geom, &why)) { delete c; return fail(REVO_ERR_INVALID_ARG, why); }
   build_track_params(c, &c->tp);
+  struct Guard { revo_ctx* c; ~Guard() { if (c) ctx_free(c); } } guard{c};  // a HIP failure below frees what exists so far
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHECK(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
@@ -333,22 +335,24 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipMemset(c->d_hist8, 0, sizeof(int) * 8));
   HIPCHECK(hipMemset(c->d_vote_done, 0, sizeof(unsigned)));
   HIPCHECK(hipHostMalloc((void**)&c->h_hist8, sizeof(int) * 8));
+  guard.c = nullptr;
   *out = c;
   return REVO_OK;
 }
 
 static void ctx_free(revo_ctx* c) {
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->build_stream);
-  hipStreamSynchronize(c->stream);
+  if (c->build_stream) hipStreamSynchronize(c->build_stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
   for (auto& p : c->past) { hipFree(p.d_pts); hipFree(p.d_n); }
   for (auto& p : c->past_pool) { hipFree(p.d_pts); hipFree(p.d_n); }
-  hipStreamDestroy(c->build_stream);
+  if (c->build_stream) hipStreamDestroy(c->build_stream);
   for (FrameSet* fs : c->pool) frameset_destroy(fs);
   hipHostFree(c->h_desc); hipHostFree(c->h_res); hipHostFree(c->h_eval); hipFree(c->d_mail);
   hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8); hipFree(c->d_vote_done);
   hipFree(c->d_pcl);
-  hipStreamDestroy(c->stream);
+  if (c->stream) hipStreamDestroy(c->stream);
+  (void)hipGetLastError();  // a partially built context frees null handles on purpose
   delete c;
 }
 static void ctx_ref(revo_ctx* c) { c->refs.fetch_add(1); }
@@ -777,6 +781,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   ctx_ref(c);
   int rc = frameset_create(c, 2 * n_pairs, false, &b->fs);
   if (rc) { delete b; ctx_unref(c); return rc; }
+  struct Guard { revo_batch* b; ~Guard() { if (b) revo_batch_destroy(b); } } guard{b};  // frees a partial batch on failure
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
   HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
@@ -788,16 +793,19 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
   for (int i = 0; i < n_pairs; ++i) fill_desc(&b->h_descs[i], &b->views[2 * i], &b->views[2 * i + 1], nullptr, nullptr);
   HIPCHECK(hipStreamSynchronize(c->stream));  // frameset_create's memset
+  guard.b = nullptr;
   *out = b;
   return REVO_OK;
 }
 extern "C" void revo_batch_destroy(revo_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
-  hipStreamSynchronize(b->stream);
+  if (b->stream) hipStreamSynchronize(b->stream);
   hipHostFree(b->h_descs); hipFree(b->d_descs); hipFree(b->d_mail);
-  hipEventDestroy(b->ev0); hipEventDestroy(b->ev1); hipEventDestroy(b->ev_upload);
-  hipStreamDestroy(b->stream);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev_upload) hipEventDestroy(b->ev_upload);
+  if (b->stream) hipStreamDestroy(b->stream);
   frameset_destroy(b->fs);
   revo_ctx* c = b->ctx;
   delete b;
