@@ -176,6 +176,8 @@ def main():
 
     # ---- correctness of what was timed (never skipped work): poses vs ground truth
     res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), a.pairs)
+    if any(r["flags"] & (2 | 8) for r in res):
+        raise SystemExit("bench: the tracker flagged invalid results (flags %s)" % [r["flags"] for r in res])
     errs = [synth.pose_error(r["R"], r["T"], g) for r, g in zip(res, gt)]
     rot_med = float(np.median([e[0] for e in errs]))
     tr_med = float(np.median([e[1] for e in errs]))

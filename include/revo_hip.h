@@ -242,7 +242,12 @@ typedef struct revo_pair_result {
   int32_t status;   /* tracker.cpp:351-352 */
   int32_t evals[REVO_MAX_LEVELS]; /* residual evaluations per level */
   int32_t flags;    /* bit0: init pose reset to identity (tracker.cpp:277-282);
-                       bit1: non-orthogonal input R */
+                       bit1: non-orthogonal input R (the single-pair calls return REVO_ERR_NOT_ORTHOGONAL);
+                       bit2: evaluation cap hit (6000 residual evaluations; the reference's bound is 100 outer
+                             iterations x unbounded retries) -- pose is the last accepted one;
+                       bit3: the workgroups of this pair could not exchange their partial sums in time (not
+                             co-resident, e.g. the device is shared): R, T are NOT valid (the single-pair
+                             calls return REVO_ERR_HIP) */
   int32_t n_pts0;   /* N_0 of the current frame */
 } revo_pair_result;
 

@@ -603,6 +603,7 @@ extern "C" int revo_optimizer_track_level(revo_ctx* c, const revo_pyr* ref, cons
   if (rc) return rc;
   const revo_pair_result& r = *c->h_res;
   if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
+  if (r.flags & 8) return fail(REVO_ERR_HIP, "tracker: the workgroups of the pair could not exchange partial sums in time (device shared?)");
   memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
   if (err) *err = r.err;
   if (info) { info->good_pts_edges = r.good; info->bad_pts_edges = r.bad; info->sum_error_unweighted = 0.f; info->sum_error_weighted = 0.f; }
@@ -643,6 +644,7 @@ extern "C" int revo_tracker_track_frames(revo_ctx* c, const revo_pyr* ref, const
   if (rc) return rc;
   const revo_pair_result& r = *c->h_res;
   if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
+  if (r.flags & 8) return fail(REVO_ERR_HIP, "tracker: the workgroups of the pair could not exchange partial sums in time (device shared?)");
   memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
   if (err) *err = r.err;
   if (status) *status = r.status;
