@@ -288,6 +288,7 @@ def main():
         drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
         dt_seq = time.perf_counter() - t0
         ate_seq = synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
+        rpe_t, rpe_r = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
         cpu_seq = None
         if a.cpu_baseline != "off":  # the same stream through the oracle's REVO::start restatement, 1 core
             from oracle import ro
@@ -302,6 +303,7 @@ def main():
             cpu_trk_only = min(n, 40) / t_trk
         out["single_stream"] = {"frames_per_s": n / dt_seq, "frames": n, "keyframes": drv.nKeyFrames,
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
+                                "rpe_rmse_per_frame": {"trans_m": rpe_t, "rot_rad": rpe_r},
                                 "cpu_oracle_frames_per_s_1core": cpu_seq,
                                 "cpu_oracle_frames_per_s_2core_pipelined_derived": cpu_seq_2core if cpu_seq else None,
                                 "cpu_oracle_tracker_only_frames_per_s_1core": cpu_trk_only if cpu_seq else None,

@@ -43,7 +43,7 @@ def main(argv=None):
         if drawer is not None:
             out = drawer.saveModel(os.path.join(model_dir, name) if len(io["datasets"]) > 1 else model_dir)
             print("model: %d points of %d keyframes -> %s, %s" % (drawer.nPts, len(drawer.vpKfsF), out[0], out[1]))
-        gt_file = os.path.join(folder, "groundtruth.txt")
+        gt_file = os.path.join(folder, "groundtruth.txt")  # positions only: ATE (the RPE evaluator needs full poses)
         if os.path.exists(gt_file):
             gt = tum.read_groundtruth_positions(gt_file)
             est, ref = [], []

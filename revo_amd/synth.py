@@ -203,6 +203,22 @@ def ate_rmse(est, gt):
     return float(np.sqrt((err ** 2).sum(1).mean()))
 
 
+def rpe_rmse(est, gt, delta=1):
+    """Relative pose error over `delta` frames (TUM evaluate_rpe.py semantics, fixed frame delta):
+    E_i = (Q_i^-1 Q_{i+d})^-1 (P_i^-1 P_{i+d}); returns (translational RMSE in metres, rotational
+    RMSE in rad)."""
+    tr, ro = [], []
+    for i in range(len(est) - delta):
+        Pd = np.linalg.inv(np.asarray(est[i], np.float64)) @ np.asarray(est[i + delta], np.float64)
+        Qd = np.linalg.inv(np.asarray(gt[i], np.float64)) @ np.asarray(gt[i + delta], np.float64)
+        E = np.linalg.inv(Qd) @ Pd
+        tr.append(float(np.linalg.norm(E[:3, 3])))
+        ro.append(rot_angle(np.eye(3), E[:3, :3]))
+    if not tr:
+        return 0.0, 0.0
+    return float(np.sqrt(np.mean(np.square(tr)))), float(np.sqrt(np.mean(np.square(ro))))
+
+
 def rot_angle(Ra, Rb):
     """Angle (rad) of Ra^T Rb via the skew part (|sin| of the angle): accurate for the tiny
     angles compared here, where arccos((trace-1)/2) has a ~3e-4 rad float32 noise floor."""

@@ -72,3 +72,29 @@ def test_tum_layout_roundtrip(tmp_path):
         assert np.abs(raw.astype(np.float32) / 5000.0 - depth0).max() <= 0.5 / 5000.0 + 1e-6
     gt = tum.read_groundtruth_positions(folder + "/groundtruth.txt")
     assert len(gt) == 4
+
+
+def test_ate_and_rpe_evaluators():
+    """In-repo trajectory metrics (TUM evaluate_ate / evaluate_rpe semantics)."""
+    import numpy as np
+    from revo_amd import synth
+    rng = np.random.default_rng(0)
+    gt = [np.eye(4)]
+    for _ in range(30):
+        gt.append(gt[-1] @ synth.se3_exp(np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.01, 3)])))
+    # a rigidly moved copy has zero ATE (alignment) and zero RPE (relative motion is unchanged)
+    M = synth.se3_exp([0.3, -0.2, 0.5, 0.2, -0.1, 0.4])
+    moved = [M @ T for T in gt]
+    assert synth.ate_rmse(moved, gt) < 1e-9
+    rt, rr = synth.rpe_rmse(moved, gt)
+    assert rt < 1e-9 and rr < 1e-9
+    # a constant 1 cm drift per frame along x of the camera: RPE = 1 cm exactly, ATE grows with the length
+    drift = synth.se3_exp([0.01, 0, 0, 0, 0, 0])
+    est = [gt[0]]
+    for i in range(1, len(gt)):
+        est.append(est[-1] @ (np.linalg.inv(gt[i - 1]) @ gt[i]) @ drift)
+    rt, rr = synth.rpe_rmse(est, gt)
+    assert abs(rt - 0.01) < 1e-9 and rr < 1e-9
+    assert synth.ate_rmse(est, gt) > 0.02
+    rt5, _ = synth.rpe_rmse(est, gt, delta=5)
+    assert 0.03 < rt5 < 0.06
