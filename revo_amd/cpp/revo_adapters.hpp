@@ -19,6 +19,10 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -264,6 +268,61 @@ class REVO {
     return true;
   }
   int numKeyframes() const { return revo_vo_num_keyframes(vo_); }
+
+  // The reference's threading (system.cpp:96, iowrapperRGBD.cpp:279-288): `produce(*this)` runs on an IO
+  // thread and calls submit() for the next frame (returns false when the sequence is over);
+  // `consume(pose_colmajor16, newKeyframe, timestamp)` runs on the calling thread for every tracked frame.
+  // At most maxQueue pyramids are in flight.  An exception on either side stops both and is rethrown here.
+  template <class Produce, class Consume>
+  void run(Produce&& produce, Consume&& consume, int maxQueue = 4) {
+    std::mutex m;
+    std::condition_variable cv;
+    int submitted = 0, tracked = 0;
+    bool done = false, stop = false;
+    std::exception_ptr err;
+    std::thread io([&] {
+      try {
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return stop || submitted - tracked < maxQueue; });
+            if (stop) break;
+          }
+          if (!produce(*this)) break;
+          { std::lock_guard<std::mutex> lk(m); ++submitted; }
+          cv.notify_all();
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(m);
+        if (!err) err = std::current_exception();
+      }
+      { std::lock_guard<std::mutex> lk(m); done = true; }
+      cv.notify_all();
+    });
+    try {
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return submitted > tracked || done; });
+          if (submitted == tracked) break;  // done and drained
+        }
+        std::array<float, 16> pose;
+        bool kf = false;
+        double ts = 0.0;
+        trackNext(pose, &kf, &ts);
+        consume(pose, kf, ts);
+        { std::lock_guard<std::mutex> lk(m); ++tracked; }
+        cv.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(m);
+      if (!err) err = std::current_exception();
+      stop = true;
+    }
+    cv.notify_all();
+    io.join();
+    if (err) std::rethrow_exception(err);
+  }
 
  private:
   std::shared_ptr<CameraPyr> cam_;

@@ -52,6 +52,26 @@ int main(int argc, char** argv) {
   double sum = 0;
   for (float v : pcl) sum += v;
   std::printf("pcl %zu %.9g\n", pcl.size() / 8, sum);
+  // REVO::start sequencing with the reference's IO thread: 8 frames alternating the two inputs
+  {
+    revo::REVO vo(camPyr);
+    int fed = 0;
+    vo.run(
+        [&](revo::REVO& r) {
+          if (fed == 8) return false;
+          const bool odd = (fed & 1) != 0;
+          r.submit((const uint8_t*)(odd ? cb.data() : rb.data()), (size_t)w * 3, (const float*)(odd ? cd.data() : rd.data()), (size_t)w * 4,
+                   fed / 30.0);
+          ++fed;
+          return true;
+        },
+        [&](const std::array<float, 16>& pose, bool kf, double ts) {
+          std::printf("vo %d %.6f", kf ? 1 : 0, ts);
+          for (int i = 0; i < 16; ++i) std::printf(" %.9g", pose[i]);
+          std::printf("\n");
+        });
+    std::printf("vokf %d\n", vo.numKeyframes());
+  }
   // error behaviour: tracking against a non-keyframe must fail like "optimizationStructure not built!"
   try {
     tracker.trackFrames(R, T, error, currPyr, kfPyr);

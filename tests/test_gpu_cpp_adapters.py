@@ -17,7 +17,7 @@ def test_cpp_adapter_host_matches_python_host(tmp_path):
     pair = synth.make_pair(11, s)
     exe = str(tmp_path / "adapter_track")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "adapter_track.cpp"),
-                           "-L" + os.path.join(ROOT, "revo_amd"), "-lrevo_hip",
+                           "-pthread", "-L" + os.path.join(ROOT, "revo_amd"), "-lrevo_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "revo_amd")])
     names = []
     for tag in ("ref", "curr"):
@@ -26,7 +26,8 @@ def test_cpp_adapter_host_matches_python_host(tmp_path):
             np.ascontiguousarray(pair[tag][k]).tofile(p)
             names.append(p)
     out = subprocess.check_output([exe, "320", "240"] + names, timeout=120).decode()
-    vals = {ln.split()[0]: ln.split()[1:] for ln in out.strip().splitlines()}
+    vo_lines = [ln.split()[1:] for ln in out.strip().splitlines() if ln.startswith("vo ")]
+    vals = {ln.split()[0]: ln.split()[1:] for ln in out.strip().splitlines() if not ln.startswith("vo ")}
     R_cpp = np.array(vals["R"], np.float32).reshape(3, 3).T
     T_cpp = np.array(vals["T"], np.float32)
 
@@ -49,3 +50,13 @@ def test_cpp_adapter_host_matches_python_host(tmp_path):
     assert int(vals["pcl"][0]) == len(pcl) and abs(float(vals["pcl"][1]) - float(pcl.astype(np.float64).sum())) < 1e-3
     er, et = synth.pose_error(R_cpp, T_cpp, pair["T_ref_curr"])
     assert er < 3e-3 and et < 5e-3
+
+    # revo::REVO::run (IO thread + consumer loop in C++) vs the Python driver on the same 8 frames: same bits
+    from revo_amd import vo
+    frames = [(pair["curr" if i % 2 else "ref"][0], pair["curr" if i % 2 else "ref"][1], i / 30.0) for i in range(8)]
+    drv = vo.REVO(s)
+    res = drv.run(frames)
+    assert len(vo_lines) == 8 and int(vals["vokf"][0]) == drv.nKeyFrames
+    for ln, (M, kf) in zip(vo_lines, res):
+        assert int(ln[0]) == int(kf)
+        assert np.array_equal(np.array(ln[2:], np.float32).reshape(4, 4).T, M)
