@@ -55,22 +55,26 @@ static inline int reflect101(int i, int n) {
  * dst = (sum + 128) >> 8, output (x,y) centred on source (2x,2y).
  * w,h must be even (reference sizes come from Camera width*scale). */
 void ro_pyrdown_u8(const uint8_t* src, int w, int h, uint8_t* dst) {
+  /* separable form (horizontal sums of the 5 source rows an output row needs, then the vertical
+   * combination): the same integers as the 25-tap definition, at the cost OpenCV's routine has */
   const int dw = w / 2, dh = h / 2;
-  static const int k[5] = {1, 4, 6, 4, 1};
-  for (int y = 0; y < dh; ++y)
-    for (int x = 0; x < dw; ++x) {
-      int sum = 0;
-      for (int j = -2; j <= 2; ++j) {
-        const int sy = reflect101(2 * y + j, h);
-        int rowsum = 0;
-        for (int i = -2; i <= 2; ++i) {
-          const int sx = reflect101(2 * x + i, w);
-          rowsum += k[i + 2] * src[(size_t)sy * w + sx];
-        }
-        sum += k[j + 2] * rowsum;
+  int* hrow = (int*)malloc(sizeof(int) * 5 * (size_t)dw);
+  for (int y = 0; y < dh; ++y) {
+    for (int j = 0; j < 5; ++j) {
+      const uint8_t* r = src + (size_t)reflect101(2 * y + j - 2, h) * w;
+      int* hr = hrow + (size_t)j * dw;
+      for (int x = 0; x < dw; ++x) {
+        const int c = 2 * x;
+        if (c >= 2 && c + 2 < w) hr[x] = r[c - 2] + r[c + 2] + 4 * (r[c - 1] + r[c + 1]) + 6 * r[c];
+        else hr[x] = r[reflect101(c - 2, w)] + r[reflect101(c + 2, w)] + 4 * (r[reflect101(c - 1, w)] + r[reflect101(c + 1, w)]) + 6 * r[c];
       }
+    }
+    for (int x = 0; x < dw; ++x) {
+      const int sum = hrow[x] + hrow[4 * (size_t)dw + x] + 4 * (hrow[(size_t)dw + x] + hrow[3 * (size_t)dw + x]) + 6 * hrow[2 * (size_t)dw + x];
       dst[(size_t)y * dw + x] = (uint8_t)((sum + 128) >> 8);
     }
+  }
+  free(hrow);
 }
 
 /* ImgPyramidRGBD::FilterSubsampleWithHoles, imgpyramidrgbd.h:218-249. */
@@ -272,36 +276,60 @@ int ro_edges3d(const uint8_t* edges, const float* depth, int w, int h, float fx,
 void ro_edt(const uint8_t* edges, int w, int h, float* dt) {
   const int INF = 1 << 29;
   int* g2 = (int*)malloc(sizeof(int) * (size_t)w * h);
-  for (int x = 0; x < w; ++x) {
-    int dist = INF;
-    for (int y = 0; y < h; ++y) { /* nearest edge above */
-      if (edges[(size_t)y * w + x] > 0) dist = 0; else if (dist < INF) dist++;
-      g2[(size_t)y * w + x] = dist;
-    }
-    dist = INF;
-    for (int y = h - 1; y >= 0; --y) { /* nearest edge below */
-      if (edges[(size_t)y * w + x] > 0) dist = 0; else if (dist < INF) dist++;
-      if (dist < g2[(size_t)y * w + x]) g2[(size_t)y * w + x] = dist;
-    }
-    for (int y = 0; y < h; ++y) {
-      const int d = g2[(size_t)y * w + x];
-      g2[(size_t)y * w + x] = d >= INF ? INF : d * d;
+  /* column pass as two row sweeps (top-down, bottom-up) with one running distance per column: the same
+   * integers as a per-column walk, but sequential in memory (a per-column walk over the row-major image is
+   * cache-hostile and would make this CPU baseline slower than the OpenCV routine it stands for) */
+  int* run = (int*)malloc(sizeof(int) * (size_t)w);
+  for (int x = 0; x < w; ++x) run[x] = INF;
+  for (int y = 0; y < h; ++y) { /* nearest edge above */
+    const uint8_t* e = edges + (size_t)y * w;
+    int* g = g2 + (size_t)y * w;
+    for (int x = 0; x < w; ++x) {
+      int d = run[x];
+      if (e[x] > 0) d = 0; else if (d < INF) d++;
+      run[x] = d;
+      g[x] = d;
     }
   }
-  /* row pass: lower envelope, exact integer version of the F-H scan */
+  for (int x = 0; x < w; ++x) run[x] = INF;
+  for (int y = h - 1; y >= 0; --y) { /* nearest edge below, then square */
+    const uint8_t* e = edges + (size_t)y * w;
+    int* g = g2 + (size_t)y * w;
+    for (int x = 0; x < w; ++x) {
+      int d = run[x];
+      if (e[x] > 0) d = 0; else if (d < INF) d++;
+      run[x] = d;
+      const int m = d < g[x] ? d : g[x];
+      g[x] = m >= INF ? INF : m * m;
+    }
+  }
+  free(run);
+  /* row pass: lower envelope of parabolas (F-H scan).  The intersection abscissae are kept as exact
+   * rationals num/den (den > 0) and compared by cross-multiplication in int64: exact, and no division
+   * per candidate (OpenCV avoids it with reciprocal tables). */
   int* v = (int*)malloc(sizeof(int) * (size_t)w);
-  double* z = (double*)malloc(sizeof(double) * ((size_t)w + 1));
+  long long* zn = (long long*)malloc(sizeof(long long) * ((size_t)w + 1));
+  int* zd = (int*)malloc(sizeof(int) * ((size_t)w + 1));
   for (int y = 0; y < h; ++y) {
     const int* f = g2 + (size_t)y * w;
     int k = -1;
     for (int q = 0; q < w; ++q) {
       if (f[q] >= INF) continue;
-      while (k >= 0) {
+      const long long fq = (long long)f[q] + (long long)q * q;
+      while (k > 0) {
         const int p = v[k];
-        const double s = ((double)(f[q] + q * q) - (double)(f[p] + p * p)) / (2.0 * (q - p));
-        if (s <= z[k]) --k; else { ++k; v[k] = q; z[k] = s; break; }
+        const long long num = fq - ((long long)f[p] + (long long)p * p);
+        const int den = 2 * (q - p);
+        if (num * zd[k] <= zn[k] * den) --k; else break; /* s <= z[k]: parabola p is hidden */
       }
-      if (k < 0) { k = 0; v[0] = q; z[0] = -1e300; }
+      if (k < 0) { k = 0; v[0] = q; zn[0] = 0; zd[0] = 1; /* z[0] = -inf: never compared */ }
+      else {
+        const int p = v[k];
+        ++k;
+        v[k] = q;
+        zn[k] = fq - ((long long)f[p] + (long long)p * p);
+        zd[k] = 2 * (q - p);
+      }
     }
     float* out = dt + (size_t)y * w;
     if (k < 0) { /* no edge anywhere in the image (all columns empty) */
@@ -311,13 +339,14 @@ void ro_edt(const uint8_t* edges, int w, int h, float* dt) {
     const int kmax = k;
     k = 0;
     for (int q = 0; q < w; ++q) {
-      while (k < kmax && z[k + 1] < (double)q) ++k;
+      while (k < kmax && zn[k + 1] < (long long)q * zd[k + 1]) ++k;
       const int p = v[k];
       const int d2 = (q - p) * (q - p) + f[p];
       out[q] = sqrtf((float)d2);
     }
   }
-  free(z); free(v); free(g2);
+  free(zn); free(zd);
+  free(v); free(g2);
 }
 
 /* ImgPyramidRGBD::buildOptimizationStructure, imgpyramidrgbd.cpp:255-276.
