@@ -283,10 +283,13 @@ def main():
         seq = synth.make_sequence(7, s, n, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
         stream_frames = [(f[0], f[1], f[2]) for f in seq]
         vo.REVO(s, cameraPyr=cam).run(stream_frames[:6])  # warm-up (pools, first-touch)
-        drv = vo.REVO(s, cameraPyr=cam)
-        t0 = time.perf_counter()
-        drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
-        dt_seq = time.perf_counter() - t0
+        runs = []
+        for _ in range(3):  # host-side jitter (threads, PCIe) is large for a 25 ms run: best of three, all reported
+            drv = vo.REVO(s, cameraPyr=cam)
+            t0 = time.perf_counter()
+            drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
+            runs.append(time.perf_counter() - t0)
+        dt_seq = min(runs)
         ate_seq = synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
         rpe_t, rpe_r = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
         cpu_seq = None
@@ -301,7 +304,8 @@ def main():
             # the reference builds pyramids on its IO thread (system.cpp:96): 2-core pipelined rate (derived)
             cpu_seq_2core = min(n, 40) / max(t_pyr, t_kf + t_trk)
             cpu_trk_only = min(n, 40) / t_trk
-        out["single_stream"] = {"frames_per_s": n / dt_seq, "frames": n, "keyframes": drv.nKeyFrames,
+        out["single_stream"] = {"frames_per_s": n / dt_seq, "frames_per_s_runs": [n / t for t in runs], "frames": n,
+                                "keyframes": drv.nKeyFrames,
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
                                 "rpe_rmse_per_frame": {"trans_m": rpe_t, "rot_rad": rpe_r},
                                 "cpu_oracle_frames_per_s_1core": cpu_seq,
