@@ -84,7 +84,8 @@ def main():
     from revo_amd.settings import ImgPyramidSettings, TrackerSettings
     hist = tuple([20, 10, 5] + [0] * 3) if a.width == 640 else tuple([20, 10, 5, 0, 0, 0])
     s = ImgPyramidSettings.scaled(a.width, a.height, a.levels, hist_patch=hist)
-    seeds = [rank * a.pairs + i for i in range(a.pairs)]
+    from revo_amd import parallel
+    seeds = parallel.shard_pairs(world * a.pairs, rank, world)  # static block partition: rank g owns [g*B/G, (g+1)*B/G)
     jobs = [(sd, a.width, a.height, a.levels) for sd in seeds]
     nproc = a.render_procs or max(1, min(16, usable_cpus() // max(1, world), a.pairs))
     t0 = time.time()
@@ -128,7 +129,6 @@ def main():
     d_dep = torch.from_numpy(dep).to(dev)
     d_ress = [torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     d_res = d_ress[0]
-    d_all = torch.zeros(world * a.pairs * 96, dtype=torch.uint8, device=dev) if world > 1 else None
     s_track = torch.cuda.Stream(device=dev)   # also carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev) if nbuf == 2 else s_track
     torch.cuda.set_stream(s_track)
@@ -137,6 +137,8 @@ def main():
     ev_built = [torch.cuda.Event() for _ in range(nbuf)]
     ev_tracked = [torch.cuda.Event() for _ in range(nbuf)]
     counter = [0]
+    gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
+    d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
         k = counter[0] % nbuf
@@ -150,7 +152,7 @@ def main():
         else:
             bts[k].track(d_bgr.data_ptr(), d_dep.data_ptr(), d_ress[k].data_ptr(), stream=stream)
         if world > 1:  # the only collective: 96 B x pairs per rank, RCCL over xGMI
-            dist.all_gather_into_tensor(d_all, d_ress[k])
+            gathered[0] = parallel.gather_records(d_ress[k], world, out=d_all)
         ev_tracked[k].record(s_track)
 
     for _ in range(a.warmup):
@@ -167,10 +169,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = parallel.max_over_ranks(elapsed, world, device=dev)
+    if world > 1 and gathered[0] is not None and gathered[0].numel() != world * a.pairs * parallel.RECORD_BYTES:
+        raise SystemExit("bench: gathered record buffer has the wrong size")
     d_res = d_ress[(counter[0] - 1) % nbuf]
     bt = bts[(counter[0] - 1) % nbuf]
 

@@ -15,14 +15,18 @@ def shard_pairs(global_pairs, rank, world):
     return list(range(rank * per, (rank + 1) * per))
 
 
-def gather_records(local_records, world, group=None):
+def gather_records(local_records, world, group=None, out=None):
     """local_records: uint8 tensor [pairs*96] on this rank's device -> uint8 tensor
-    [world*pairs*96] holding every rank's records in rank order (on every rank)."""
+    [world*pairs*96] holding every rank's records in rank order (on every rank).
+    `out`: optional preallocated result tensor (steady-state loops reuse one)."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local_records
-    out = torch.empty(world * local_records.numel(), dtype=torch.uint8, device=local_records.device)
+    if out is None:
+        out = torch.empty(world * local_records.numel(), dtype=torch.uint8, device=local_records.device)
+    elif out.numel() != world * local_records.numel() or out.dtype != torch.uint8:
+        raise ValueError("out must be a uint8 tensor of world * len(local_records) elements")
     dist.all_gather_into_tensor(out, local_records, group=group)
     return out
 

@@ -79,6 +79,8 @@ for i, p in enumerate(mine):
     rec[i, 12] = 0.5 * p
 local = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
 allrec = parallel.gather_records(local, world)
+pre = torch.zeros(world * local.numel(), dtype=torch.uint8)
+assert parallel.gather_records(local, world, out=pre) is pre and torch.equal(pre, allrec)
 assert allrec.numel() == world * 4 * 96
 R, T, err = parallel.records_to_poses(allrec.numpy().tobytes(), 8)
 for p in range(8):
