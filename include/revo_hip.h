@@ -267,6 +267,10 @@ int revo_batch_track(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
 /* Stage-wise variants used by bench.py for per-kernel timing. */
 int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
                      void* stream);
+/* revo_batch_build for raw uint16 depth [2*n_pairs][H][W] (depth = raw * (float)(1/scale),
+ * iowrapperRGBD.cpp:326-327, fused into the first build kernel). */
+int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const uint16_t* d_depth_raw,
+                         double depth_scale_factor, void* stream);
 int revo_batch_track_only(revo_batch* b, const float* h_init_RT,
                           revo_pair_result* d_results, void* stream);
 int revo_batch_sync(revo_batch* b, void* stream);

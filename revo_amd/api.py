@@ -318,6 +318,10 @@ class BatchTracker:
     def build(self, d_bgr, d_depth, stream=None):
         check(_lib.lib().revo_batch_build(self._h, d_bgr, d_depth, stream))
 
+    def build_u16(self, d_bgr, d_depth_raw, depth_scale_factor, stream=None):
+        """build() for raw uint16 depth (device pointer); the metres conversion is fused into the build."""
+        check(_lib.lib().revo_batch_build_u16(self._h, d_bgr, d_depth_raw, float(depth_scale_factor), stream))
+
     def track_only(self, d_results, init_RT=None, stream=None):
         keep, ptr = self._init(init_RT)
         check(_lib.lib().revo_batch_track_only(self._h, ptr, d_results, stream))

@@ -853,6 +853,21 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   return REVO_OK;
 }
 
+// Same as revo_batch_build for raw 16-bit depth (the reference's on-disk format): the conversion
+// depth = raw * (float)(1/scale) of iowrapperRGBD.cpp:326-327 runs inside the first build kernel.
+extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const uint16_t* d_depth_raw,
+                                    double depth_scale_factor, void* stream) {
+  if (!b || !d_bgr || !d_depth_raw) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (!(depth_scale_factor > 0.0)) return fail(REVO_ERR_INVALID_ARG, "depth_scale_factor must be positive");
+  HIPCHECK(hipSetDevice(b->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s);
+  launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);
+  HIPCHECK(hipGetLastError());
+  for (auto& v : b->views) v.table_built = false;
+  return REVO_OK;
+}
+
 extern "C" int revo_batch_track(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, const float* h_init_RT,
                                 revo_pair_result* d_results, void* stream) {
   int rc = revo_batch_build(b, d_bgr, d_depth, stream);

@@ -393,6 +393,43 @@ def test_empty_edge_list_is_safe(api, ro):
     assert np.isnan(err) and np.allclose(R, np.eye(3)) and np.all(T == 0)
 
 
+def test_batch_u16_depth_matches_the_u16_single_frame_path(api, ro):
+    """revo_batch_build_u16: raw 16-bit depth (the reference's on-disk format, iowrapperRGBD.cpp:326-327)
+    converted inside the batched build == the single-frame u16 entry point == the oracle on the converted
+    depth, and the tracker result equals the float-depth batch fed with that conversion."""
+    import torch
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    n_pairs = 2
+    pairs = [synth.make_pair(40 + i, s) for i in range(n_pairs)]
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    bgr = np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])
+    raw = np.stack([np.clip(p[k][1] * 5000.0, 0, 65535).astype(np.uint16) for p in pairs for k in ("ref", "curr")])
+    dep = np.stack([ro.u16_to_depth(r, 5000.0) for r in raw])
+    d_bgr, d_raw, d_dep = torch.from_numpy(bgr).cuda(), torch.from_numpy(raw).cuda(), torch.from_numpy(dep).cuda()
+    res = []
+    for use_u16 in (True, False):
+        bt = api.BatchTracker(cam, n_pairs)
+        d_res = torch.zeros(n_pairs * 96, dtype=torch.uint8, device="cuda")
+        if use_u16:
+            bt.build_u16(d_bgr.data_ptr(), d_raw.data_ptr(), 5000.0)
+        else:
+            bt.build(d_bgr.data_ptr(), d_dep.data_ptr())
+        bt.track_only(d_res.data_ptr())
+        bt.sync()
+        res.append(d_res.cpu().numpy().tobytes())
+        if use_u16:
+            for f in range(2 * n_pairs):
+                view = bt.frame(f, s)
+                single = api.ImgPyramidRGBD(s, cam, bgr[f], raw[f], depth_scale_factor=5000.0)
+                op = ro.Pyramid(s, bgr[f], dep[f])
+                for lvl in range(3):
+                    assert_same("bu16_depth", view.returnDepth(lvl), single.returnDepth(lvl))
+                    assert_same("bu16_depth_o", view.returnDepth(lvl), op.read(PLANE_DEPTH, lvl))
+                    assert_same("bu16_pts", view.return3DEdges(lvl), op.read(PLANE_EDGES3D, lvl))
+    assert res[0] == res[1]
+
+
 def test_batch_matches_single_and_full_size_properties(api, ro):
     import torch
     s = tum_settings(4)
