@@ -171,6 +171,28 @@ def test_dense_edges_640_take_the_unstaged_compaction_path(api, ro):
     assert gp.return3DEdges(0).shape[0] > 10 * 4096  # > 4096 per strip on average (10 strips)
 
 
+@pytest.mark.parametrize("w,h,levels", [(64, 48, 2), (136, 88, 2), (200, 120, 2), (328, 248, 2), (72, 40, 1), (1120, 624, 3)])
+def test_unusual_sizes_bit_exact(api, ro, w, h, levels):
+    """Widths that are not multiples of the 64-pixel tiles / strips, heights that are not multiples of the
+    16-row tiles or 32-row chunks, on smooth random images with depth holes: every plane bit-exact."""
+    import scipy.ndimage as ndi
+    s = ImgPyramidSettings.scaled(w, h, levels, hist_patch=(0, 0, 0, 0, 0, 0))
+    r = np.random.default_rng(w * 1000 + h)
+    g = ndi.gaussian_filter(r.uniform(0, 255, (h, w, 3)), (2.0, 2.0, 0))
+    bgr = np.clip((g - g.mean()) * 9 + 128, 0, 255).astype(np.uint8)
+    depth = r.uniform(0.05, 5.5, (h, w)).astype(np.float32)
+    depth[r.uniform(0, 1, (h, w)) < 0.15] = 0.0
+    cam = api.CameraPyr(s)
+    gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+    op = ro.Pyramid(s, bgr, depth)
+    gp.makeKeyframe()
+    op.makeKeyframe()
+    compare_pyramid("size_%dx%d" % (w, h), gp, op, s, True)
+    assert gp.return3DEdges(0).shape[0] > 0
+    for dense in (False, True):
+        assert_same("size_pcl", gp.generateColoredPcl(levels - 1, dense), op.generateColoredPcl(levels - 1, dense))
+
+
 def test_u16_depth_entry_point(api, ro):
     s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
     bgr, depth = synth.make_pair(1, s)["ref"]
