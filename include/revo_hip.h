@@ -305,6 +305,12 @@ int revo_vo_submit_u16(revo_vo* vo, const uint8_t* bgr, size_t bgr_stride,
 int revo_vo_track_next(revo_vo* vo, float pose_colmajor[16], int* new_keyframe,
                        double* timestamp);
 int revo_vo_queued(const revo_vo* vo);
+/* Two-thread use (the reference's IO thread + consumer loop, system.cpp:96): revo_vo_set_max_queue(n > 0)
+ * (re-)opens the stream and makes revo_vo_submit* block while n pyramids wait (n <= 0: never block); the producer ends the stream with revo_vo_close; the
+ * consumer calls revo_vo_wait_frame (1: a frame is queued, 0: closed and drained) before revo_vo_track_next. */
+int revo_vo_set_max_queue(revo_vo* vo, int max_queue);
+int revo_vo_close(revo_vo* vo);
+int revo_vo_wait_frame(revo_vo* vo);
 int revo_vo_num_keyframes(const revo_vo* vo);
 /* The current keyframe (kfPyr) and its pose in the world (getTransKFtoWorld), as REVO::start hands
  * them to the map drawer after a keyframe change (system.cpp:165-167,235-237).  The handle is

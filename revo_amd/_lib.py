@@ -102,6 +102,9 @@ def lib():
     L.revo_vo_track_next.argtypes = [vp, f32p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.revo_vo_queued.argtypes = [vp]
     L.revo_vo_keyframe.argtypes = [vp, vpp, f32p]
+    L.revo_vo_set_max_queue.argtypes = [vp, C.c_int]
+    L.revo_vo_close.argtypes = [vp]
+    L.revo_vo_wait_frame.argtypes = [vp]
     L.revo_vo_num_keyframes.argtypes = [vp]
     _lib = L
     return L

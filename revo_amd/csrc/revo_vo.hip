@@ -2,6 +2,7 @@
 // Host-only code: the device work is what revo_pyramid_* / revo_tracker_* enqueue.
 #include <cstring>
 #include <deque>
+#include <condition_variable>
 #include <mutex>
 
 #include "../../include/revo_hip.h"
@@ -65,6 +66,9 @@ struct revo_vo {
   revo_ctx* ctx;
   std::deque<Frame> queue;  // mPyrQueue, iowrapperRGBD.h:166-167
   std::mutex qmu;           // mtx of the reference's queue: submit may run on an IO thread (system.cpp:96)
+  std::condition_variable qcv;  // queue became non-empty / got room / was closed
+  int max_queue = 0;        // > 0: submit blocks while this many pyramids wait (back-pressure on the IO thread)
+  bool closed = false;      // the producer announced the end of the stream (iowrapperRGBD's hasMoreImages() == false)
   Frame kf{nullptr, 0, M4::identity()}, prev{nullptr, 0, M4::identity()};
   Pose last, before_last;
   M4 T_NM1_N = M4::identity();
@@ -100,6 +104,29 @@ extern "C" int revo_vo_queued(const revo_vo* v) {
   return (int)v->queue.size();
 }
 extern "C" int revo_vo_num_keyframes(const revo_vo* v) { return v ? v->n_keyframes : 0; }
+// Hand-off between the IO thread and the consumer loop inside the library (the reference: mPyrQueue + its
+// mutex, hasMoreImages()).  max_queue > 0 makes submit block while that many pyramids wait.
+extern "C" int revo_vo_set_max_queue(revo_vo* v, int max_queue) {
+  if (!v) return REVO_ERR_INVALID_ARG;
+  { std::lock_guard<std::mutex> lk(v->qmu); v->max_queue = max_queue; v->closed = false; }  // (re-)opens the stream
+  v->qcv.notify_all();
+  return REVO_OK;
+}
+// the producer has no more frames: revo_vo_wait_frame returns 0 once the queue has drained
+extern "C" int revo_vo_close(revo_vo* v) {
+  if (!v) return REVO_ERR_INVALID_ARG;
+  { std::lock_guard<std::mutex> lk(v->qmu); v->closed = true; }
+  v->qcv.notify_all();
+  return REVO_OK;
+}
+// blocks until a frame is queued (returns 1) or the stream is closed and drained (returns 0)
+extern "C" int revo_vo_wait_frame(revo_vo* v) {
+  if (!v) return REVO_ERR_INVALID_ARG;
+  std::unique_lock<std::mutex> lk(v->qmu);
+  v->qcv.wait(lk, [&] { return !v->queue.empty() || v->closed; });
+  return v->queue.empty() ? 0 : 1;
+}
+
 // kfPyr and kfPyr->getTransKFtoWorld() (system.cpp:165-167,235-237): what the viewer / model export consume
 extern "C" int revo_vo_keyframe(const revo_vo* v, revo_pyr** kf_out, float T_w_kf[16]) {
   if (!v || !v->kf.pyr) return REVO_ERR_INVALID_ARG;
@@ -115,7 +142,12 @@ extern "C" int revo_vo_submit(revo_vo* v, const uint8_t* bgr, size_t bgr_stride,
   Frame f{nullptr, ts, M4::identity()};
   const int rc = revo_pyramid_create(v->ctx, bgr, bgr_stride, depth, depth_stride, ts, &f.pyr);
   if (rc) return rc;
-  { std::lock_guard<std::mutex> lk(v->qmu); v->queue.push_back(f); }
+  {
+    std::unique_lock<std::mutex> lk(v->qmu);
+    v->qcv.wait(lk, [&] { return v->max_queue <= 0 || (int)v->queue.size() < v->max_queue; });
+    v->queue.push_back(f);
+  }
+  v->qcv.notify_all();
   return REVO_OK;
 }
 
@@ -125,7 +157,12 @@ extern "C" int revo_vo_submit_u16(revo_vo* v, const uint8_t* bgr, size_t bgr_str
   Frame f{nullptr, ts, M4::identity()};
   const int rc = revo_pyramid_create_u16(v->ctx, bgr, bgr_stride, depth_raw, depth_stride, depth_scale_factor, ts, &f.pyr);
   if (rc) return rc;
-  { std::lock_guard<std::mutex> lk(v->qmu); v->queue.push_back(f); }
+  {
+    std::unique_lock<std::mutex> lk(v->qmu);
+    v->qcv.wait(lk, [&] { return v->max_queue <= 0 || (int)v->queue.size() < v->max_queue; });
+    v->queue.push_back(f);
+  }
+  v->qcv.notify_all();
   return REVO_OK;
 }
 
@@ -139,6 +176,7 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
     curr = v->queue.front();
     v->queue.pop_front();
   }
+  v->qcv.notify_all();
   int rc, new_kf = 0, status = 0;
   const M4 I = M4::identity();
   if (ts_out) *ts_out = curr.ts;

@@ -112,39 +112,32 @@ class REVO:
             out.append(self.track_next())
             return out
         import threading
-        slots = threading.Semaphore(max_queue)  # bounds the pyramids in flight (each holds its device planes)
-        ready = threading.Semaphore(0)
-        state = {"n": 0, "done": False, "err": None}
+        L = _lib.lib()
+        check(L.revo_vo_set_max_queue(self._h, int(max_queue)))  # bounded queue inside the library, stream open
+        state = {"err": None}
 
         def producer():
             try:
                 for f in frames:
-                    slots.acquire()
                     if state["err"] is not None:
                         break
-                    self.submit(*f[:3])
-                    state["n"] += 1
-                    ready.release()
+                    self.submit(*f[:3])  # blocks while max_queue pyramids wait
             except BaseException as e:  # surfaced on the consumer thread
                 state["err"] = e
-            state["done"] = True
-            ready.release()
+            finally:
+                L.revo_vo_close(self._h)  # end of stream: the consumer's wait returns 0 once the queue drained
 
         th = threading.Thread(target=producer, name="revo-io", daemon=True)
         th.start()
         out = []
         try:
-            while True:
-                ready.acquire()
-                if len(out) == state["n"] and state["done"]:
-                    break
+            while L.revo_vo_wait_frame(self._h) == 1:
                 out.append(self.track_next())
-                slots.release()
         except BaseException as e:
             state["err"] = state["err"] or e
-            slots.release()
             raise
         finally:
+            L.revo_vo_set_max_queue(self._h, 0)  # never leave the producer blocked on a full queue
             th.join()
         if state["err"] is not None:
             raise state["err"]
