@@ -19,7 +19,6 @@
 #pragma once
 #include <algorithm>
 #include <array>
-#include <condition_variable>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -275,51 +274,36 @@ class REVO {
   // At most maxQueue pyramids are in flight.  An exception on either side stops both and is rethrown here.
   template <class Produce, class Consume>
   void run(Produce&& produce, Consume&& consume, int maxQueue = 4) {
+    check(revo_vo_set_max_queue(vo_, maxQueue), "REVO::run");  // bounded queue inside the library, stream open
     std::mutex m;
-    std::condition_variable cv;
-    int submitted = 0, tracked = 0;
-    bool done = false, stop = false;
     std::exception_ptr err;
+    bool stop = false;
     std::thread io([&] {
       try {
         for (;;) {
-          {
-            std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return stop || submitted - tracked < maxQueue; });
-            if (stop) break;
-          }
-          if (!produce(*this)) break;
-          { std::lock_guard<std::mutex> lk(m); ++submitted; }
-          cv.notify_all();
+          { std::lock_guard<std::mutex> lk(m); if (stop) break; }
+          if (!produce(*this)) break;  // submit() blocks while maxQueue pyramids wait
         }
       } catch (...) {
         std::lock_guard<std::mutex> lk(m);
         if (!err) err = std::current_exception();
       }
-      { std::lock_guard<std::mutex> lk(m); done = true; }
-      cv.notify_all();
+      revo_vo_close(vo_);  // end of stream: revo_vo_wait_frame returns 0 once the queue has drained
     });
     try {
-      for (;;) {
-        {
-          std::unique_lock<std::mutex> lk(m);
-          cv.wait(lk, [&] { return submitted > tracked || done; });
-          if (submitted == tracked) break;  // done and drained
-        }
+      while (revo_vo_wait_frame(vo_) == 1) {
         std::array<float, 16> pose;
         bool kf = false;
         double ts = 0.0;
         trackNext(pose, &kf, &ts);
         consume(pose, kf, ts);
-        { std::lock_guard<std::mutex> lk(m); ++tracked; }
-        cv.notify_all();
       }
     } catch (...) {
       std::lock_guard<std::mutex> lk(m);
       if (!err) err = std::current_exception();
       stop = true;
     }
-    cv.notify_all();
+    revo_vo_set_max_queue(vo_, 0);  // never leave the IO thread blocked on a full queue
     io.join();
     if (err) std::rethrow_exception(err);
   }
