@@ -207,9 +207,10 @@ static int pick_cluster(const revo_ctx* c, int n_pairs) {
   const int resident = c->num_cus * c->blocks_per_cu;
   int cl = (int)(0.75 * resident) / std::max(1, n_pairs);
   if (cl > TRACK_MAX_CLUSTER) cl = TRACK_MAX_CLUSTER;
-  if (const char* e = getenv("REVO_TRACK_CLUSTER")) {  // tuning knob, clamped to what fits
+  if (const char* e = getenv("REVO_TRACK_CLUSTER")) {  // tuning knob: may go up to everything the device can hold
     const int want = atoi(e);
-    if (want >= 1 && want < cl) cl = want;
+    const int hard = std::min(TRACK_MAX_CLUSTER, resident / std::max(1, n_pairs));
+    if (want >= 1) cl = std::min(want, std::max(1, hard));
   }
   if (cl < 1) cl = 1;
   return cl;
