@@ -2,11 +2,12 @@
 // (ImgPyramidRGBD ctor, imgpyramidrgbd.cpp:43-96,173-229) and the keyframe
 // promotion (makeKeyframe, imgpyramidrgbd.cpp:231-276).
 //
-// All stages are HBM-bound integer/byte streaming or small stencils: coalesced
-// dword/dwordx4 row accesses, LDS tiles for the 5x5 / 3x3 stencils and the
-// union-find hysteresis, blockIdx.z = frame, blockIdx.x decodes level + tile so
-// one launch covers every level of every frame in the batch.  No MFMA: there
-// is no contraction anywhere on this path.
+// Integer/byte streaming and small stencils: coalesced dword/dwordx4 row accesses, an LDS
+// tile for the 3x3 stencil + union-find hysteresis, LDS staging where a block's output is a
+// contiguous range (ordered compaction), blockIdx.z = frame, blockIdx.x decodes level + tile
+// so one launch covers every level of every frame in the batch.  No MFMA: there is no
+// contraction anywhere on this path.  What binds each kernel (HBM for k_gray_depth, VALU issue for
+// k_canny_nms, dependent-load latency for the hysteresis passes, ...) is tabulated in DESIGN.md 3.
 //
 // Exactness: every integer stage is bit-exact by construction; float stages
 // keep the reference's operation order and are compiled with -ffp-contract=off.
