@@ -616,9 +616,20 @@ __global__ void __launch_bounds__(256) k_hist(PyrGeom g, FramePlanes pl, int row
       const uint4 v = *reinterpret_cast<const uint4*>(edges + (size_t)y * lv.w + x0);
       if ((v.x | v.y | v.z | v.w) == 0) continue;
       const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+      // walk the 16 pixels once: the tile index advances at tile boundaries (one division per chunk, not
+      // per pixel) and a tile gets ONE LDS atomic with its count instead of one per edge pixel
+      int t = x0 / lv.patch, next = (t + 1) * lv.patch, c = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if ((vw[k >> 2] >> (8 * (k & 3))) & 0xffu) atomicAdd(&s_cnt[(x0 + k) / lv.patch], 1);
+      for (int k = 0; k < 16; ++k) {
+        if (x0 + k == next) {
+          if (c) atomicAdd(&s_cnt[t], c);
+          c = 0;
+          ++t;
+          next += lv.patch;
+        }
+        c += ((vw[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1 : 0;
+      }
+      if (c) atomicAdd(&s_cnt[t], c);
     }
   } else {
     for (int i = tid; i < lv.patch * bw; i += 256) {
