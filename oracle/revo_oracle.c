@@ -114,14 +114,20 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
  * inside cv::Canny (imgpyramidrgbd.cpp:184). */
 void ro_sobel3(const uint8_t* g, int w, int h, int16_t* dx, int16_t* dy) {
   for (int y = 0; y < h; ++y) {
-    const int ym = clampi(y - 1, 0, h - 1), yp = clampi(y + 1, 0, h - 1);
-    for (int x = 0; x < w; ++x) {
+    const uint8_t* rm = g + (size_t)clampi(y - 1, 0, h - 1) * w;
+    const uint8_t* r0 = g + (size_t)y * w;
+    const uint8_t* rp = g + (size_t)clampi(y + 1, 0, h - 1) * w;
+    int16_t* ox = dx + (size_t)y * w;
+    int16_t* oy = dy + (size_t)y * w;
+    /* the two border columns with BORDER_REPLICATE, the interior without clamps (vectorisable) */
+    for (int x = 0; x < w; x += (w > 1 ? w - 1 : 1)) {
       const int xm = clampi(x - 1, 0, w - 1), xp = clampi(x + 1, 0, w - 1);
-      const int a = g[(size_t)ym * w + xm], b = g[(size_t)ym * w + x], c = g[(size_t)ym * w + xp];
-      const int d = g[(size_t)y * w + xm], f = g[(size_t)y * w + xp];
-      const int p = g[(size_t)yp * w + xm], q = g[(size_t)yp * w + x], r = g[(size_t)yp * w + xp];
-      dx[(size_t)y * w + x] = (int16_t)((c + 2 * f + r) - (a + 2 * d + p));
-      dy[(size_t)y * w + x] = (int16_t)((p + 2 * q + r) - (a + 2 * b + c));
+      ox[x] = (int16_t)((rm[xp] + 2 * r0[xp] + rp[xp]) - (rm[xm] + 2 * r0[xm] + rp[xm]));
+      oy[x] = (int16_t)((rp[xm] + 2 * rp[x] + rp[xp]) - (rm[xm] + 2 * rm[x] + rm[xp]));
+    }
+    for (int x = 1; x < w - 1; ++x) {
+      ox[x] = (int16_t)((rm[x + 1] + 2 * r0[x + 1] + rp[x + 1]) - (rm[x - 1] + 2 * r0[x - 1] + rp[x - 1]));
+      oy[x] = (int16_t)((rp[x - 1] + 2 * rp[x] + rp[x + 1]) - (rm[x - 1] + 2 * rm[x] + rm[x + 1]));
     }
   }
 }
