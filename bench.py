@@ -137,6 +137,7 @@ def main():
     ev_built = [torch.cuda.Event() for _ in range(nbuf)]
     ev_tracked = [torch.cuda.Event() for _ in range(nbuf)]
     counter = [0]
+    timing, track_events = [False], []  # the dominant kernel is timed live in the timed steps (roofline)
     gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
     d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if world > 1 else None
 
@@ -148,7 +149,14 @@ def main():
             bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=s_build.cuda_stream)
             ev_built[k].record(s_build)
             s_track.wait_event(ev_built[k])
-            bts[k].track_only(d_ress[k].data_ptr(), stream=s_track.cuda_stream)
+            if timing[0]:  # HIP events around the tracker launch, on its stream, inside the timed region
+                e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e_a.record(s_track)
+                bts[k].track_only(d_ress[k].data_ptr(), stream=s_track.cuda_stream)
+                e_b.record(s_track)
+                track_events.append((e_a, e_b))
+            else:
+                bts[k].track_only(d_ress[k].data_ptr(), stream=s_track.cuda_stream)
         else:
             bts[k].track(d_bgr.data_ptr(), d_dep.data_ptr(), d_ress[k].data_ptr(), stream=stream)
         if world > 1:  # the only collective: 96 B x pairs per rank, RCCL over xGMI
@@ -161,6 +169,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    timing[0] = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -169,6 +178,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timing[0] = False
     elapsed = parallel.max_over_ranks(elapsed, world, device=dev)
     if world > 1 and gathered[0] is not None and gathered[0].numel() != world * a.pairs * parallel.RECORD_BYTES:
         raise SystemExit("bench: gathered record buffer has the wrong size")
@@ -183,8 +193,11 @@ def main():
     rot_med = float(np.median([e[0] for e in errs]))
     tr_med = float(np.median([e[1] for e in errs]))
 
-    # ---- roofline of the dominant kernel (k_track), timed live with HIP events on its stream
-    ms_track = bt.time_tracker(d_res.data_ptr(), reps=10, stream=stream)
+    # ---- roofline of the dominant kernel (k_track): HIP events on its stream around every launch of the
+    # timed region (next to the other stream's build kernels); `kernel_ms_alone` re-times it with nothing else
+    # running (revo_batch_time_tracker)
+    ms_track_alone = bt.time_tracker(d_res.data_ptr(), reps=10, stream=stream)
+    ms_track = (float(np.mean([ea.elapsed_time(eb) for ea, eb in track_events])) if track_events else ms_track_alone)
     npts = np.zeros((a.pairs, a.levels), np.int64)
     for i in range(a.pairs):
         view = bt.frame(2 * i + 1, s)
@@ -263,7 +276,9 @@ def main():
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
-            "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track,
+            "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track, "kernel_ms_alone": ms_track_alone,
+            "frac_alone": b_trk / (ms_track_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "timing": "HIP events on the tracker's stream around each of the %d timed launches" % max(1, len(track_events)),
             "measured_copy_gbs": copy_gbs,  # on-box device-to-device copy ceiling (read + write bytes), for context
         },
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},

@@ -126,6 +126,7 @@ struct revo_batch {
   PairDesc* h_descs; PairDesc* d_descs;
   unsigned long long* d_mail;
   unsigned mail_epoch = 0;
+  bool identity_uploaded = false;  // d_descs already holds the identity initial poses (nothing to upload)
   int cluster;
   hipStream_t stream;
   hipEvent_t ev0, ev1, ev_upload;
@@ -829,6 +830,8 @@ extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float
 }
 
 static int batch_upload_init(revo_batch* b, const float* h_init_RT, hipStream_t s) {
+  if (!h_init_RT && b->identity_uploaded) return REVO_OK;  // same descriptors as last time: no copy on the stream
+  b->identity_uploaded = (h_init_RT == nullptr);
   // the previous upload reads h_descs asynchronously: let it finish before rewriting the poses
   HIPCHECK(hipEventSynchronize(b->ev_upload));
   for (int i = 0; i < b->n_pairs; ++i) {
