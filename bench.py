@@ -74,17 +74,28 @@ def main():
     ap.add_argument("--render-procs", type=int, default=0, help="0 = auto")
     ap.add_argument("--no-overlap", action="store_true", help="single batch, single stream (no build/track overlap)")
     ap.add_argument("--single-stream-frames", type=int, default=60, help="0 = skip the sequential-VO side measurement")
+    ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the world-size-1 RCCL group")
     a = ap.parse_args()
 
+    from revo_amd import parallel
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
+        # env:// rendezvous on 127.0.0.1); rank 0 prints the JSON line on this process's stdout
+        codes = parallel.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus)
+        bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+        if bad:
+            raise SystemExit("bench: ranks failed (rank, exit code): %s" % bad)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and a.gpus != world and rank == 0:
+        print("bench: --gpus %d ignored, the launcher set WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
 
     # ---- synthetic input (rendered on the host BEFORE any GPU state exists) ----
     from revo_amd.settings import ImgPyramidSettings, TrackerSettings
     hist = tuple([20, 10, 5] + [0] * 3) if a.width == 640 else tuple([20, 10, 5, 0, 0, 0])
     s = ImgPyramidSettings.scaled(a.width, a.height, a.levels, hist_patch=hist)
-    from revo_amd import parallel
     seeds = parallel.shard_pairs(world * a.pairs, rank, world)  # static block partition: rank g owns [g*B/G, (g+1)*B/G)
     jobs = [(sd, a.width, a.height, a.levels) for sd in seeds]
     nproc = a.render_procs or max(1, min(16, usable_cpus() // max(1, world), a.pairs))
@@ -110,11 +121,24 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench: rank %d needs GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The path's only collective runs through RCCL at every N, N = 1 included (the world-size-1
+    # path is the single-GPU CI of the multi-GPU job).
+    group_error = None
+    if world > 1 or not a.no_collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(parallel.free_port()))
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        except Exception as e:  # noqa: BLE001 -- N = 1 can still be measured without the group; N > 1 cannot
+            if world > 1:
+                raise
+            group_error = "%s: %s" % (type(e).__name__, e)
+    use_group = dist.is_initialized()
 
     from revo_amd import api, synth
     cam = api.CameraPyr(s, device=local_rank)
@@ -127,7 +151,10 @@ def main():
     bt = bts[0]
     d_bgr = torch.from_numpy(bgr).to(dev)
     d_dep = torch.from_numpy(dep).to(dev)
-    d_ress = [torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    # every step keeps its own result records, so that ALL of them are checked after the timed region
+    n_slots = a.warmup + a.steps
+    d_res_all = torch.zeros(max(1, n_slots) * a.pairs * 96, dtype=torch.uint8, device=dev)
+    d_ress = [d_res_all[i * a.pairs * 96:(i + 1) * a.pairs * 96] for i in range(max(1, n_slots))]
     d_res = d_ress[0]
     s_track = torch.cuda.Stream(device=dev)   # also carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev) if nbuf == 2 else s_track
@@ -139,10 +166,11 @@ def main():
     counter = [0]
     timing, track_events = [False], []  # the dominant kernel is timed live in the timed steps (roofline)
     gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
-    d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if world > 1 else None
+    d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if use_group else None
 
     def step():
         k = counter[0] % nbuf
+        d_out = d_ress[counter[0] % len(d_ress)]
         counter[0] += 1
         if nbuf == 2:
             s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
@@ -152,21 +180,21 @@ def main():
             if timing[0]:  # HIP events around the tracker launch, on its stream, inside the timed region
                 e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e_a.record(s_track)
-                bts[k].track_only(d_ress[k].data_ptr(), stream=s_track.cuda_stream)
+                bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
                 e_b.record(s_track)
                 track_events.append((e_a, e_b))
             else:
-                bts[k].track_only(d_ress[k].data_ptr(), stream=s_track.cuda_stream)
+                bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
         else:
-            bts[k].track(d_bgr.data_ptr(), d_dep.data_ptr(), d_ress[k].data_ptr(), stream=stream)
-        if world > 1:  # the only collective: 96 B x pairs per rank, RCCL over xGMI
-            gathered[0] = parallel.gather_records(d_ress[k], world, out=d_all)
+            bts[k].track(d_bgr.data_ptr(), d_dep.data_ptr(), d_out.data_ptr(), stream=stream)
+        if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1)
+            gathered[0] = parallel.gather_records(d_out, world, out=d_all)
         ev_tracked[k].record(s_track)
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_group:
         dist.barrier()
     torch.cuda.synchronize()
     timing[0] = True
@@ -174,21 +202,31 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_group:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing[0] = False
     elapsed = parallel.max_over_ranks(elapsed, world, device=dev)
-    if world > 1 and gathered[0] is not None and gathered[0].numel() != world * a.pairs * parallel.RECORD_BYTES:
-        raise SystemExit("bench: gathered record buffer has the wrong size")
-    d_res = d_ress[(counter[0] - 1) % nbuf]
+    d_res = d_ress[(counter[0] - 1) % len(d_ress)]
     bt = bts[(counter[0] - 1) % nbuf]
+    if use_group:  # the gathered buffer of the last step holds this rank's records at its rank offset
+        got = gathered[0]
+        if got is None or got.numel() != world * a.pairs * parallel.RECORD_BYTES:
+            raise SystemExit("bench: gathered record buffer has the wrong size")
+        mine = got[rank * a.pairs * 96:(rank + 1) * a.pairs * 96]
+        if not torch.equal(mine, d_res):
+            raise SystemExit("bench: the RCCL gather did not return this rank's records")
 
-    # ---- correctness of what was timed (never skipped work): poses vs ground truth
-    res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), a.pairs)
-    if any(r["flags"] & (2 | 8) for r in res):
-        raise SystemExit("bench: the tracker flagged invalid results (flags %s)" % [r["flags"] for r in res])
+    # ---- correctness of what was timed (never skipped work): the flags of EVERY step, poses vs ground truth
+    all_res = api.results_from_buffer(d_res_all.cpu().numpy().tobytes(), n_slots * a.pairs)
+    bad_flags = [(i // a.pairs, i % a.pairs, r["flags"]) for i, r in enumerate(all_res) if r["flags"] & (2 | 4 | 8)]
+    if bad_flags:
+        raise SystemExit("bench: the tracker flagged invalid results (step, pair, flags): %s" % bad_flags[:8])
+    res = all_res[(n_slots - 1) * a.pairs:]
+    first = all_res[:a.pairs]
+    if n_slots > 1 and any(not (np.array_equal(x["R"], y["R"]) and np.array_equal(x["T"], y["T"])) for x, y in zip(first, res)):
+        raise SystemExit("bench: the same inputs gave different poses in different steps")
     errs = [synth.pose_error(r["R"], r["T"], g) for r, g in zip(res, gt)]
     rot_med = float(np.median([e[0] for e in errs]))
     tr_med = float(np.median([e[1] for e in errs]))
@@ -251,6 +289,16 @@ def main():
             del src, dst
         except RuntimeError:
             copy_gbs = None
+    gather_us = None
+    if use_group:  # the collective alone (latency-bound: 96 B x pairs per rank)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            parallel.gather_records(d_res, world, out=d_all)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_us = e0.elapsed_time(e1) * 1e3 / 20
     out = {
         "metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference",
         "value": world * a.pairs * a.steps / elapsed,
@@ -281,6 +329,9 @@ def main():
             "timing": "HIP events on the tracker's stream around each of the %d timed launches" % max(1, len(track_events)),
             "measured_copy_gbs": copy_gbs,  # on-box device-to-device copy ceiling (read + write bytes), for context
         },
+        "collective": {"backend": "nccl (RCCL)" if use_group else None, "executed_every_step": bool(use_group),
+                       "bytes_per_rank": a.pairs * parallel.RECORD_BYTES, "us_per_all_gather_alone": gather_us,
+                       "error": group_error},
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},
         "pose_error_vs_ground_truth": {"rot_rad_median": rot_med, "trans_m_median": tr_med},
         "mean_edge_points_lvl0": float(npts[:, 0].mean()),
@@ -368,7 +419,7 @@ def main():
         out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1,7 +1,16 @@
 """Multi-GPU layer of the batched mode: one process per GPU, frame-pairs
 sharded statically across ranks, NO data-path collective; the only exchange is one
 all_gather of the fixed 96-byte pair records (RCCL over xGMI on GPUs, gloo in the CPU
-tests).  At 96 B x pairs the collective is latency-bound; nothing is reduced."""
+tests).  At 96 B x pairs the collective is latency-bound; nothing is reduced.
+
+A process group of world size 1 is a real group: when one is initialised, the gather and
+the max-time reduction go through the backend (RCCL on a GPU) exactly like at N > 1, so the
+single-GPU CI exercises the same code path the 8-GPU job runs."""
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 
 RECORD_BYTES = 96
@@ -15,13 +24,19 @@ def shard_pairs(global_pairs, rank, world):
     return list(range(rank * per, (rank + 1) * per))
 
 
+def _group_live():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_records(local_records, world, group=None, out=None):
     """local_records: uint8 tensor [pairs*96] on this rank's device -> uint8 tensor
     [world*pairs*96] holding every rank's records in rank order (on every rank).
-    `out`: optional preallocated result tensor (steady-state loops reuse one)."""
+    `out`: optional preallocated result tensor (steady-state loops reuse one).
+    Without a process group a single rank's records are their own gather."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not _group_live():
         return local_records
     if out is None:
         out = torch.empty(world * local_records.numel(), dtype=torch.uint8, device=local_records.device)
@@ -34,7 +49,7 @@ def gather_records(local_records, world, group=None, out=None):
 def max_over_ranks(seconds, world, device="cpu"):
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not _group_live():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -46,3 +61,50 @@ def records_to_poses(buf, n):
     a = np.frombuffer(bytes(buf), dtype=np.float32).reshape(n, RECORD_BYTES // 4)
     R = a[:, :9].reshape(n, 3, 3).transpose(0, 2, 1).copy()
     return R, a[:, 9:12].copy(), a[:, 12].copy()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rendezvous_env(rank, world, local_rank=None, port=None, base=None):
+    """Environment of one rank of a single-node job (torch.distributed env:// rendezvous on 127.0.0.1)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank if local_rank is None else local_rank), WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port or free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
+    return env
+
+
+def spawn_ranks(script, argv, world, timeout=None):
+    """`python script argv` once per rank (one process per GPU: LOCAL_RANK = rank), rank 0 inheriting this
+    process's stdout.  Returns the exit codes; a rank that fails takes the others down."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = rendezvous_env(r, world, port=port)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [None] * world
+    try:
+        import time
+        t0 = time.time()
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes) or (timeout and time.time() - t0 > timeout):
+                break
+            time.sleep(0.05)
+    finally:
+        for i, p in enumerate(procs):  # exactly the processes started here, by handle
+            if p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            codes[i] = p.returncode
+    return codes

@@ -113,3 +113,61 @@ def test_shard_validation():
     with pytest.raises(ValueError):
         parallel.shard_pairs(10, 0, 4)
     assert parallel.shard_pairs(256, 7, 8) == list(range(224, 256))
+
+
+SPAWNED = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from revo_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+local = torch.full((2 * 96,), rank + 1, dtype=torch.uint8)
+allrec = parallel.gather_records(local, world)
+assert allrec.numel() == world * 2 * 96 and int(allrec[-1]) == world
+assert parallel.max_over_ranks(float(rank), world) == float(world - 1)
+dist.destroy_process_group()
+if rank == 0:
+    print("spawned world", world, sys.argv[1:])
+if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+    sys.exit(3)
+"""
+
+
+def test_spawn_ranks_is_what_bench_uses_for_gpus_n(tmp_path, capfd):
+    """`python bench.py --gpus N` without a launcher starts N ranks through parallel.spawn_ranks."""
+    from revo_amd import parallel
+    script = tmp_path / "spawned.py"
+    script.write_text(SPAWNED % ROOT)
+    assert parallel.spawn_ranks(str(script), ["--x", "1"], 2, timeout=120) == [0, 0]
+    assert "spawned world 2 ['--x', '1']" in capfd.readouterr().out
+    codes = parallel.spawn_ranks(str(script), ["fail"], 2, timeout=120)
+    assert codes[1] == 3  # a failing rank is reported, the job does not hang
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "parallel.spawn_ranks(" in src and '"WORLD_SIZE" not in os.environ and a.gpus > 1' in src
+
+
+def test_world1_group_goes_through_the_backend():
+    """With a live process group of size 1 the gather and the max-time are real collectives (gloo here, RCCL
+    on the GPU box: tests/test_gpu_multi.py)."""
+    script = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from unittest import mock
+from revo_amd import parallel
+dist.init_process_group("gloo", rank=0, world_size=1)
+local = torch.arange(192, dtype=torch.int64).to(torch.uint8)
+with mock.patch.object(dist, "all_gather_into_tensor", wraps=dist.all_gather_into_tensor) as ag, \
+     mock.patch.object(dist, "all_reduce", wraps=dist.all_reduce) as ar:
+    out = parallel.gather_records(local, 1)
+    t = parallel.max_over_ranks(2.5, 1)
+assert ag.call_count == 1 and ar.call_count == 1 and out is not local and torch.equal(out, local) and t == 2.5
+dist.destroy_process_group()
+assert parallel.gather_records(local, 1) is local  # no group: a single rank's records are their own gather
+""" % ROOT
+    from revo_amd import parallel
+    env = parallel.rendezvous_env(0, 1)
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
