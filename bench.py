@@ -89,6 +89,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON record: native libraries print there too (RCCL's version
+    # banner is flushed to fd 1 at exit), so fd 1 points at stderr until the record is written to the real one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if "WORLD_SIZE" in os.environ and a.gpus != world and rank == 0:
         print("bench: --gpus %d ignored, the launcher set WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
 
@@ -418,7 +423,9 @@ def main():
                       "same per-pair work as cpu_baseline" % (total, ncore, all_t)}
         out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
+    torch.cuda.synchronize()
     if dist.is_initialized():
         dist.destroy_process_group()
 

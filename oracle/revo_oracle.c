@@ -20,6 +20,19 @@
 
 static int g_accum_double = 0;
 void ro_set_accum_double(int on) { g_accum_double = on; }
+/* LM trace (test/analysis aid): one entry per residual evaluation after a level's first,
+ * lvl*2 + accepted.  Not thread-safe: single-thread analysis only. */
+static int g_lm_trace_on = 0, g_lm_trace_n = 0;
+static unsigned char g_lm_trace[16384];
+void ro_lm_trace(int on) { g_lm_trace_on = on; g_lm_trace_n = 0; }
+int ro_lm_trace_get(unsigned char* dst, int cap) {
+  const int n = g_lm_trace_n < cap ? g_lm_trace_n : cap;
+  memcpy(dst, g_lm_trace, (size_t)n);
+  return g_lm_trace_n;
+}
+static void lm_trace_push(int lvl, int accepted) {
+  if (g_lm_trace_on && g_lm_trace_n < (int)sizeof(g_lm_trace)) g_lm_trace[g_lm_trace_n++] = (unsigned char)(lvl * 2 + accepted);
+}
 
 static double now_s(void) {
   struct timespec ts;
@@ -984,6 +997,7 @@ float ro_optimizer_track_level(ro_tracker* t, const ro_pyramid* ref, const ro_py
       ro_se3_mul(qe, te, q, tr, qn, tn);
       ro_quat_to_R(qn, Rn);
       const float error = calc_error_and_buffers(t, ref, curr, Rn, tn, resInfo, lvl); ++n_eval;
+      lm_trace_push(lvl, error < lastErr);
       if (error < lastErr) {
         memcpy(q, qn, sizeof(q)); memcpy(tr, tn, sizeof(tr));
         if (error / lastErr > t->os.convergence_eps[lvl]) iteration = t->os.max_its_per_lvl[lvl];
