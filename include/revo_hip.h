@@ -206,6 +206,11 @@ int revo_optimizer_eval(revo_ctx* ctx, const revo_pyr* ref, const revo_pyr* curr
                         revo_residual_info* info, float* err, float A[36],
                         float b[6]);
 
+/* Eigen::Matrix<float,6,1> inc = A.ldlt().solve(b) after A(i,i) *= 1 + LM_lambda (optimizer.cpp:258-262), as the
+ * tracker kernel computes it (float LDL^T pivoted on the largest |diagonal|, pseudo-inverse of D), for n systems:
+ * in = n x 43 floats {A[36] symmetric, b[6], lambda}, x6 = n x 6.  Exposed for the parity tests of the solver. */
+int revo_optimizer_solve6(revo_ctx* ctx, int n, const float* A36_b6_lambda, float* x6);
+
 /* ---- TrackerNew ------------------------------------------------------------ */
 
 /* TrackerStatus TrackerNew::trackFrames(R, T, error, refFrame, currFrame),

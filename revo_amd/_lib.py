@@ -11,7 +11,8 @@ from .settings import (ImgPyramidSettings, OptimizerSettings, TrackerSettings, R
                        PairResult, MAX_LEVELS)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librevo_hip.so")
+# REVO_HIP_SO: an alternative build of the same library (profiling builds under profiles/); never a fallback
+SO_PATH = os.environ.get("REVO_HIP_SO") or os.path.join(_HERE, "librevo_hip.so")
 HEADER = os.path.join(_HERE, "..", "include", "revo_hip.h")
 
 u8p = C.POINTER(C.c_uint8)
@@ -77,6 +78,7 @@ def lib():
     L.revo_pyramid_colored_pcl.argtypes = [vp, C.c_int, C.c_int, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.revo_optimizer_track_level.argtypes = [vp, vp, vp, f32p, f32p, C.c_int, C.POINTER(ResidualInfo), f32p]
     L.revo_optimizer_eval.argtypes = [vp, vp, vp, f32p, f32p, C.c_int, C.POINTER(ResidualInfo), f32p, f32p, f32p]
+    L.revo_optimizer_solve6.argtypes = [vp, C.c_int, f32p, f32p]
     L.revo_tracker_track_frames.argtypes = [vp, vp, vp, f32p, f32p, f32p, C.POINTER(C.c_int),
                                             C.POINTER(ResidualInfo), i32p]
     L.revo_tracker_assess_quality.argtypes = [vp, f32p, vp, C.POINTER(C.c_int), i32p, i32p]

@@ -236,6 +236,18 @@ class Optimizer:
         return err.value, info, A.reshape(6, 6), b
 
 
+def solve6(cameraPyr, A, b, lam):
+    """A.ldlt().solve(b) with A(i,i) *= 1 + lam (optimizer.cpp:258-262) on the device.
+    A [n,6,6] symmetric, b [n,6], lam [n] -> x [n,6]."""
+    A = np.asarray(A, np.float32).reshape(-1, 36)
+    n = A.shape[0]
+    buf = np.concatenate([A, np.asarray(b, np.float32).reshape(n, 6), np.asarray(lam, np.float32).reshape(n, 1)], axis=1)
+    buf = np.ascontiguousarray(buf, np.float32)
+    x = np.empty((n, 6), np.float32)
+    check(_lib.lib().revo_optimizer_solve6(cameraPyr._h, n, _p(buf, f32p), _p(x, f32p)))
+    return x
+
+
 class TrackerNew:
     """system/tracker.h:56-105."""
 

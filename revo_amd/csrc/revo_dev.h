@@ -22,8 +22,9 @@ struct LevelGeom {
   int nchunk;          // row-chunks per column for the ordered compaction
   int chunk_rows;
   // launch decode helpers (prefix sums over levels)
-  int tile_base;       // first NMS tile index of this level
-  int tiles_x, tiles_y;
+  int wpr;             // 32-pixel bitmap words per row (Canny candidate / strong / edge bitmaps)
+  int nms_block_base;  // first block of this level in the k_canny_nms launch
+  int has_orig;        // fillInEdges may change this level: edgesOrigPyr is a separate plane (imgpyramidrgbd.cpp:185-195)
   int pix_base;        // sum of npix of finer levels
   int row_base;        // sum of h of finer levels
   int strip_base;      // number of 64-column strips of finer levels (compaction launch decode)
@@ -33,7 +34,7 @@ struct LevelGeom {
 struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
-  int total_tiles, total_pix, total_rows, total_strips, total_cc;
+  int total_nms_blocks, total_pix, total_rows, total_strips, total_cc;
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
   int use_edge_hist;
@@ -46,9 +47,9 @@ struct PyrGeom {
 struct FramePlanes {
   uint8_t* gray[REVO_L];
   float* depth[REVO_L];
-  uint8_t* nms[REVO_L];        // Canny map: 0 none, 1 weak candidate, 2 strong
+  uint2* cs[REVO_L];           // Canny bitmaps: per row and 32 pixels {candidate bits, strong bits} (frame stride h*wpr)
   uint8_t* edges[REVO_L];      // edgesPyr     {0,255}
-  uint8_t* edges_orig[REVO_L]; // edgesOrigPyr {0,255}
+  uint8_t* edges_orig[REVO_L]; // edgesOrigPyr {0,255}: written only for levels with has_orig (elsewhere it IS edges)
   int* scratch[REVO_L];        // CCL parent keys during the build; column g^2 during makeKeyframe
   float4* pts[REVO_L];         // edges3DPyr: (X,Y,Z,1), capacity npix per frame
   float* dt[REVO_L];           // dtPyr
@@ -74,6 +75,8 @@ struct TrackParams {
   int lvl_begin, lvl_end;         // levels to run (lvl_begin >= lvl_end), inclusive
   int check_init;                 // tracker.cpp:268
   int eval_only;                  // 1: one calcErrorAndBuffers+calculateWarpUpdate at (R,T), lvl_begin
+  int kspec;                      // LM candidates evaluated per pass: 1 full + (kspec-1) error-only retries (1..TRACK_KMAX)
+  int redundant_n;                // levels with at most this many points are evaluated by every cluster member (no exchange)
   float lambda_success_fac, lambda_fail_fac;
   float lambda_initial[REVO_L], step_size_min[REVO_L], convergence_eps[REVO_L];
   int max_its[REVO_L];
@@ -94,28 +97,22 @@ struct EvalOut {
 };
 
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
-#define NMS_TILE_W 64
-#ifndef NMS_TILE_H
-#define NMS_TILE_H 16
-#endif
-// NMS_TILE_H: multiple of 16 (64x32 measured slower: 223 vs 176 us, LDS-limited occupancy)
-#ifndef NMS_THREADS
-#define NMS_THREADS 256             // 16 threads (x 4 px) per tile row
-#endif
-#define NMS_ROWS_PER_PASS (NMS_THREADS / 16)
-#define NMS_PASSES (NMS_TILE_H / NMS_ROWS_PER_PASS)
+#define NMS_ROWS 6                  // output rows per k_canny_nms thread (8 pixels wide)
+#define REVO_HYST_LDS_MAX 163000    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
 #define TRACK_THREADS 512
 #ifndef TRACK_MAX_CLUSTER
-#define TRACK_MAX_CLUSTER 8
+#define TRACK_MAX_CLUSTER 32       // workgroups per frame-pair (one XCD holds 32 CUs)
 #endif
+#define TRACK_KMAX 4               // speculative LM candidates per pass
+#define TRACK_NVAL 48              // values a workgroup publishes per pass: 32 normal-equation + 16 error slots
 
 // ---- launchers (defined in the kernel translation units) -------------------
 void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,
                        const uint16_t* d_depth_u16, float u16_alpha, int B, hipStream_t s);
 void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s);
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
-void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
-void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 // keyframe promotion of frames f0, f0+fstride, ... (count frames)
 void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
@@ -127,6 +124,7 @@ void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_res
                   int n_pairs, unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
 void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
                       unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
+void launch_solve6(const float* d_Ab /*n x 43: A 36, b 6, lambda*/, int n, float* d_x /*n x 6*/, hipStream_t s);
 int track_blocks_per_cu();  // occupancy query of k_track (advisory)
 void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
 // past clouds of the quality vote (tracker.cpp:138-176): pose of cloud c relative to the current frame

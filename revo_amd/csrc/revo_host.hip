@@ -130,6 +130,8 @@ struct revo_batch {
   int cluster;
   hipStream_t stream;
   hipEvent_t ev0, ev1, ev_upload;
+  const revo_pair_result* last_results = nullptr;  // device records of the last track launch (revo_batch_sync decodes their flags)
+  revo_pair_result* h_flags = nullptr;             // pinned scratch for that
 };
 
 // ---------------------------------------------------------------- geometry --
@@ -172,15 +174,27 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     }
     g->fill_thr[l] = (double)(v.patch * v.patch) * 0.05;  // imgpyramidrgbd.cpp:133
     v.chunk_rows = 32; v.nchunk = (v.h + 31) / 32;
-    v.tiles_x = (v.w + NMS_TILE_W - 1) / NMS_TILE_W; v.tiles_y = (v.h + NMS_TILE_H - 1) / NMS_TILE_H;
-    v.tile_base = tile; tile += v.tiles_x * v.tiles_y;
+    v.wpr = (v.w + 31) / 32;
+    v.nms_block_base = tile; tile += (4 * v.wpr * ((v.h + NMS_ROWS - 1) / NMS_ROWS) + 255) / 256;
+    // the level's edge bitmap must fit the LDS of one workgroup (k_hyst)
+    if ((size_t)(v.h + 2) * (v.wpr + 2) * 4 > REVO_HYST_LDS_MAX) { *why = "image too large: (height + 2) x (ceil(width/32) + 2) bitmap words must fit 160 KB of LDS"; return -1; }
     v.pix_base = pix; pix += v.npix;
     v.row_base = row; row += v.h;
     v.strip_base = col; col += (v.w + 63) / 64;
     v.cc_base = cc; cc += v.w * v.nchunk;
   }
-  g->total_tiles = tile; g->total_pix = pix; g->total_rows = row; g->total_strips = col; g->total_cc = cc;
+  for (int l = 1; l < L; ++l)  // fillInEdges' gate (imgpyramidrgbd.cpp:188-195 + the patch sizes that exist)
+    g->lv[l].has_orig = (s.use_edge_hist && g->lv[l].patch > 0 && g->lv[l - 1].patch > 0) ? 1 : 0;
+  g->total_nms_blocks = tile; g->total_pix = pix; g->total_rows = row; g->total_strips = col; g->total_cc = cc;
   return 0;
+}
+
+// experiment knobs (environment): clamped integers, defaults are what ships
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = atoi(e);
+  return v < lo ? lo : (v > hi ? hi : v);
 }
 
 static void build_track_params(const revo_ctx* c, TrackParams* t) {
@@ -195,6 +209,8 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
     t->edge_distance[i] = c->os.edge_distance_lvl[i];
   }
   t->huber_edge = c->os.huber_edge; t->use_edge_filter = c->os.use_edge_filter;
+  t->kspec = env_int("REVO_TRACK_KSPEC", TRACK_KMAX, 1, TRACK_KMAX);
+  t->redundant_n = env_int("REVO_TRACK_REDUNDANT_BATCH", 400, 0, 1 << 30);
   for (int l = 0; l < c->geom.n_levels; ++l) {
     const LevelGeom& v = c->geom.lv[l];
     t->cam[l].fx = v.fx; t->cam[l].fy = v.fy; t->cam[l].cx = v.cx; t->cam[l].cy = v.cy; t->cam[l].w = v.w; t->cam[l].h = v.h;
@@ -207,8 +223,11 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
 static int pick_cluster(const revo_ctx* c, int n_pairs) {
   const int resident = c->num_cus * c->blocks_per_cu;
   int cl = (int)(0.75 * resident) / std::max(1, n_pairs);
+  // a single pair: its members share one XCD (blockIdx % 8), i.e. 32 CUs -- 16 workgroups leave half of them
+  // to the build kernels of the next frame
+  if (n_pairs == 1) cl = std::min(cl, 16);
   if (cl > TRACK_MAX_CLUSTER) cl = TRACK_MAX_CLUSTER;
-  if (const char* e = getenv("REVO_TRACK_CLUSTER")) {  // tuning knob: may go up to everything the device can hold
+  if (const char* e = getenv(n_pairs == 1 ? "REVO_TRACK_CLUSTER_ONE" : "REVO_TRACK_CLUSTER")) {  // tuning knob
     const int want = atoi(e);
     const int hard = std::min(TRACK_MAX_CLUSTER, resident / std::max(1, n_pairs));
     if (want >= 1) cl = std::min(want, std::max(1, hard));
@@ -216,7 +235,34 @@ static int pick_cluster(const revo_ctx* c, int n_pairs) {
   if (cl < 1) cl = 1;
   return cl;
 }
-static size_t mail_bytes(int n_pairs, int cluster) { return sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32; }
+
+// Tracker launches of one device are chained: a cluster's workgroups exchange partial sums inside the
+// launch, so two tracker grids must never be partially resident at the same time (each would wait for
+// members the other keeps off the CUs until the bounded spin gives up with flag 8).  A launch on another
+// stream than the previous one first waits for the previous tracker's event; launches on one stream are
+// ordered by the stream itself.  (Other PROCESSES sharing the GPU are outside this library's reach: the
+// bounded spin + flag 8 + REVO_ERR_HIP remain the answer there.)
+struct TrackChain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;
+  bool has = false;
+};
+static TrackChain g_chain[64];
+template <typename F>
+static int chained_track_launch(int device, hipStream_t s, F&& launch) {
+  TrackChain& ch = g_chain[device & 63];
+  std::lock_guard<std::mutex> lk(ch.mu);
+  if (!ch.ev) HIPCHECK(hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming));
+  if (ch.has && ch.last != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev, 0));
+  launch();
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(ch.ev, s));
+  ch.has = true;
+  ch.last = s;
+  return REVO_OK;
+}
+static size_t mail_bytes(int n_pairs, int cluster) { return sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * TRACK_NVAL; }
 
 // --------------------------------------------------------------- FrameSets --
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -238,7 +284,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       const size_t n = (size_t)v.npix * B;
       fs->p.gray[l] = (uint8_t*)take(n);
       fs->p.depth[l] = (float*)take(n * 4);
-      fs->p.nms[l] = (uint8_t*)take(n);
+      fs->p.cs[l] = (uint2*)take((size_t)v.h * v.wpr * 8 * B);
       fs->p.edges[l] = (uint8_t*)take(n);
       fs->p.edges_orig[l] = (uint8_t*)take(n);
       fs->p.scratch[l] = (int*)take(n * 4);
@@ -292,8 +338,8 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
   launch_gray_depth(g, fs->p, d_bgr, d_depth_f32, d_depth_u16, alpha, B, s);
   for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, B, s);
   launch_canny_nms(g, fs->p, B, s);
-  launch_ccl(g, fs->p, B, s);
-  launch_hist_fill(g, fs->p, B, s);
+  launch_hyst(g, fs->p, B, s);
+  launch_fill(g, fs->p, B, s);
   launch_compact(g, fs->p, B, s);
 }
 
@@ -485,7 +531,7 @@ extern "C" int revo_pyramid_read(revo_pyr* p, revo_plane what, int lvl, void* ds
     case REVO_PLANE_DEPTH: src = P.depth[lvl] + f * v.npix; esz = 4; break;
     case REVO_PLANE_EDGES: src = P.edges[lvl] + f * v.npix; break;
     case REVO_PLANE_EDGES_ORIG:  // returnOrigEdges, imgpyramidrgbd.h:67-75
-      src = ((c->ps.use_edge_hist && lvl > c->ps.pyr_max_lvl) ? P.edges_orig[lvl] : P.edges[lvl]) + f * v.npix;
+      src = (v.has_orig ? P.edges_orig[lvl] : P.edges[lvl]) + f * v.npix;  // no fill-in at this level: the clone equals edgesPyr
       break;
     case REVO_PLANE_DT:
       if (!p->is_kf) return fail(REVO_ERR_NOT_KEYFRAME, "distance transform not built: call makeKeyframe");
@@ -585,8 +631,12 @@ static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, co
                       const TrackParams& tp) {
   fill_desc(c->h_desc, ref, curr, R, T);
   { int rc = wait_ready(c, ref); if (rc) return rc; rc = wait_ready(c, curr); if (rc) return rc; }
-  launch_track_one(*c->h_desc, tp, c->h_res, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->stream);
-  HIPCHECK(hipGetLastError());
+  TrackParams tp1 = tp;
+  tp1.redundant_n = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
+  const int rc = chained_track_launch(c->device, c->stream, [&] {
+    launch_track_one(*c->h_desc, tp1, c->h_res, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->stream);
+  });
+  if (rc) return rc;
   HIPCHECK(hipStreamSynchronize(c->stream));
   return REVO_OK;
 }
@@ -630,6 +680,23 @@ extern "C" int revo_optimizer_eval(revo_ctx* c, const revo_pyr* ref, const revo_
   if (err) *err = e.mean_err;
   if (A) memcpy(A, e.A, sizeof(float) * 36);
   if (b) memcpy(b, e.b, sizeof(float) * 6);
+  return REVO_OK;
+}
+
+// inc = A.ldlt().solve(b) with A(i,i) *= 1 + lambda (optimizer.cpp:258-262) for n systems, on the device
+extern "C" int revo_optimizer_solve6(revo_ctx* c, int n, const float* A36_b6_lambda, float* x6) {
+  if (!c || !A36_b6_lambda || !x6 || n <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  float *d_in = nullptr, *d_out = nullptr;
+  HIPCHECK(hipMalloc((void**)&d_in, sizeof(float) * 43 * (size_t)n));
+  hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * 6 * (size_t)n);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, A36_b6_lambda, sizeof(float) * 43 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { launch_solve6(d_in, n, d_out, c->stream); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(x6, d_out, sizeof(float) * 6 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_in); hipFree(d_out);
+  if (e != hipSuccess) return fail(REVO_ERR_HIP, std::string("revo_optimizer_solve6: ") + hipGetErrorString(e));
   return REVO_OK;
 }
 
@@ -713,7 +780,7 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
     va.n[fr] = c->past[fr].d_n;
     ++nframes;
   }
-  const int use_orig = (c->ps.use_edge_hist && hl > c->ps.pyr_max_lvl) ? 1 : 0;
+  const int use_orig = c->geom.lv[hl].has_orig;  // returnOrigEdges(lvl), imgpyramidrgbd.h:67-75 (elsewhere the clone equals edgesPyr)
   launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, va, c->d_marks, c->d_hist8, c->d_vote_done, c->h_hist8,
               use_orig, c->stream);
   HIPCHECK(hipGetLastError());
@@ -794,6 +861,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
   for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false});
   HIPCHECK(hipHostMalloc((void**)&b->h_descs, sizeof(PairDesc) * n_pairs));
+  HIPCHECK(hipHostMalloc((void**)&b->h_flags, sizeof(revo_pair_result) * n_pairs));
   HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
   for (int i = 0; i < n_pairs; ++i) fill_desc(&b->h_descs[i], &b->views[2 * i], &b->views[2 * i + 1], nullptr, nullptr);
   HIPCHECK(hipStreamSynchronize(c->stream));  // frameset_create's memset
@@ -805,7 +873,7 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   if (b->stream) hipStreamSynchronize(b->stream);
-  hipHostFree(b->h_descs); hipFree(b->d_descs); hipFree(b->d_mail);
+  hipHostFree(b->h_descs); hipHostFree(b->h_flags); hipFree(b->d_descs); hipFree(b->d_mail);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev_upload) hipEventDestroy(b->ev_upload);
@@ -852,9 +920,10 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
-  launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
-  HIPCHECK(hipGetLastError());
-  return REVO_OK;
+  b->last_results = d_results;
+  return chained_track_launch(b->ctx->device, s, [&] {
+    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
+  });
 }
 
 // Same as revo_batch_build for raw 16-bit depth (the reference's on-disk format): the conversion
@@ -882,7 +951,18 @@ extern "C" int revo_batch_track(revo_batch* b, const uint8_t* d_bgr, const float
 extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
   if (!b) return fail(REVO_ERR_INVALID_ARG, "null batch");
   HIPCHECK(hipSetDevice(b->ctx->device));
-  HIPCHECK(hipStreamSynchronize(stream ? (hipStream_t)stream : b->stream));
+  hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  HIPCHECK(hipStreamSynchronize(s));
+  // A record with bit 3 carries no pose (its workgroups could not exchange partial sums: device shared with
+  // another process): that is an error of the call, not something to find by decoding flags.
+  if (b->last_results) {
+    HIPCHECK(hipMemcpyAsync(b->h_flags, b->last_results, sizeof(revo_pair_result) * b->n_pairs, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < b->n_pairs; ++i)
+      if (b->h_flags[i].flags & 8)
+        return fail(REVO_ERR_HIP, "tracker: pair " + std::to_string(i) + ": the workgroups of the pair could not exchange "
+                    "partial sums in time (device shared with another process?) -- its pose is not valid");
+  }
   return REVO_OK;
 }
 
@@ -904,7 +984,10 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
-    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
+    rc = chained_track_launch(b->ctx->device, s, [&] {
+      launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
+    });
+    if (rc) return rc;
     HIPCHECK(hipEventRecord(b->ev1, s));
     HIPCHECK(hipEventSynchronize(b->ev1));
     float ms = 0.f;

@@ -143,509 +143,326 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
 }
 
 // ---------------------------------------------------------------------------
-// Union-find helpers for the Canny hysteresis.  Keys are pixel indices; the
-// parent of a pixel always has a smaller key, roots point to themselves.
-// Lock-free union by atomicMin (Komura-style); placement/order independent.
-// ---------------------------------------------------------------------------
-// Loads that race with concurrent unions: agent scope is enough (L2-served); HIP's bare
-// __atomic_load_n would be SYSTEM scope, i.e. a cache-bypassing fabric read per hop.
-template <typename P>
-__device__ __forceinline__ int uf_load(P* L, int i) { return __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename P>
-__device__ __forceinline__ int uf_find(P* L, int x) {
-  int p = uf_load(L, x);
-  while (p != x) { x = p; p = uf_load(L, x); }
-  return x;
-}
-// Global variant with path halving: x's parent is replaced by its grandparent through
-// atomicMin (parents only ever decrease, and a grandparent is in the same set), which keeps
-// the root chains of giant components (textured walls) short while unions are in flight.
-__device__ __forceinline__ int uf_find_halving(int* L, int x) {
-  int p = uf_load(L, x);
-  while (p != x) {
-    const int gp = uf_load(L, p);
-    if (gp != p) atomicMin(&L[x], gp);
-    x = p;
-    p = gp;
-  }
-  return x;
-}
-// The two root walks run in lockstep: the two loads of a step are independent, so a union costs
-// max(depth_a, depth_b) round trips instead of depth_a + depth_b.
-__device__ __forceinline__ void uf_unite_global(int* L, int a, int b) {
-  int pa = uf_load(L, a), pb = uf_load(L, b);
-  for (;;) {
-    while (pa != a || pb != b) {
-      const int ga = (pa != a) ? uf_load(L, pa) : pa;
-      const int gb = (pb != b) ? uf_load(L, pb) : pb;
-      if (pa != a) {
-        if (ga != pa) atomicMin(&L[a], ga);  // path halving
-        a = pa; pa = ga;
-      }
-      if (pb != b) {
-        if (gb != pb) atomicMin(&L[b], gb);
-        b = pb; pb = gb;
-      }
-    }
-    if (a == b) return;
-    if (a > b) { const int t = a; a = b; b = t; }  // a < b: hang b under a
-    const int old = atomicMin(&L[b], a);
-    if (old == b) return;
-    b = old;  // b was re-parented meanwhile: keep that link by uniting with it too
-    pa = uf_load(L, a);
-    pb = uf_load(L, b);
-  }
-}
-// After a kernel boundary the forest is final: plain (cacheable) loads.
-__device__ __forceinline__ int uf_find_final(const int* __restrict__ L, int x) {
-  int p = L[x];
-  while (p != x) { x = p; p = L[x]; }
-  return x;
-}
-template <typename P>
-__device__ __forceinline__ void uf_unite(P* L, int a, int b) {
-  for (;;) {
-    a = uf_find(L, a);
-    b = uf_find(L, b);
-    if (a == b) return;
-    if (a > b) { const int t = a; a = b; b = t; }  // a < b: hang b under a
-    const int old = atomicMin(&L[b], a);
-    if (old == b) return;
-    b = old;  // b was re-parented meanwhile: keep that link by uniting with it too
-  }
-}
-
-// ---------------------------------------------------------------------------
 // a5 (first half): cv::Canny's Sobel 3x3 (BORDER_REPLICATE) + L2 magnitude +
-// non-maximum suppression (imgpyramidrgbd.cpp:184), 64x16 tile + halo in LDS.
-// Writes the map {0 none, 1 weak, 2 strong} and, per tile, resolves the
-// 8-connectivity of the candidates with a union-find in LDS; the global parent
-// array gets each pixel's tile-local root (as a global pixel index).
+// non-maximum suppression (imgpyramidrgbd.cpp:184).
+//
+// One thread = 8 pixels x NMS_R rows, everything in registers: no LDS, no barrier, no
+// cross-lane traffic except the final 4-lane OR that assembles a 32-pixel bitmap word.
+// Per gray row the thread loads 4 aligned words (its 8 pixels + 4 on either side; the
+// neighbours' words come out of L1) and forms, with packed 16-bit arithmetic on column
+// PAIRS, the horizontal difference d = g[c+1] - g[c-1] and smooth s = g[c-1] + 2 g[c] + g[c+1]
+// of 10 columns (x-1 .. x+8).  Three consecutive rows give dx = d0 + 2 d1 + d2 and
+// dy = s2 - s0 (exact in int16: |.| <= 1020); one v_perm packs (dx,dy) of a column and one
+// v_dot2 squares it: |grad|^2 = dx^2 + dy^2.  The magnitude rows stream through registers, so NMS
+// sees its 3x3 neighbourhood without ever storing a magnitude.  (Round 1 staged gray, magnitudes
+// and directions of a 64x16 tile in LDS and ran a union-find there: 173 VALU + 125 SALU
+// lane-instructions per pixel; this form needs ~45.)
+//
+// Output: per row and 32 pixels one {candidate, strong} pair of bitmap words -- 1/16 of the bytes
+// of the round-1 map + label planes.  Hysteresis works on the bitmaps (k_hyst).
 // ---------------------------------------------------------------------------
-// LDS geometry (byte column bc = x - (x0 - 4), so the tile's pixels sit at bc = 4..67 and every
-// 4-pixel group is word aligned):
-//   s_gw  [20][19] words : gray rows y0-2 .. y0+17, bytes bc = 0..71 (replicated at the image border)
-//   s_mag [18][76] ints  : |grad|^2 rows y0-1 .. y0+16, columns bc = 0..71 (0 outside the image)
-//   s_dxy [18][76] ints  : dx | dy << 16
-#define NMS_GW 19
-#define NMS_MS 76
-__global__ void __launch_bounds__(NMS_THREADS) k_canny_nms(PyrGeom g, FramePlanes pl) {
-  __shared__ uint32_t s_gw[NMS_TILE_H + 4][NMS_GW];
-  __shared__ __attribute__((aligned(16))) int s_mag[NMS_TILE_H + 2][NMS_MS];
-  __shared__ __attribute__((aligned(16))) int s_dxy[NMS_TILE_H + 2][NMS_MS];
-  __shared__ int s_lab[NMS_TILE_H * NMS_TILE_W];
-  const int f = g.frame0 + blockIdx.z;
-  const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
-  const LevelGeom& lv = g.lv[l];
-  const int t = blockIdx.x - lv.tile_base;
-  const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
-  const int w = lv.w, h = lv.h;
-  const uint8_t* gray = pl.gray[l] + (size_t)f * lv.npix;
-  const int tid = threadIdx.x;
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v as_s2(uint32_t v) { return __builtin_bit_cast(s2v, v); }
+__device__ __forceinline__ uint32_t as_u32(s2v v) { return __builtin_bit_cast(uint32_t, v); }
+// two bytes of the 8-byte value {hi:lo} zero-extended into the halves of a dword (v_perm_b32, selector 0x0c = 0x00)
+#define PAIR(hi, lo, sel) as_s2(__builtin_amdgcn_perm((hi), (lo), (sel)))
 
-  // phase A: gray tile as aligned words (w is a multiple of 4, x0 of 64: a word is entirely inside
-  // or entirely outside the image; outside = BORDER_REPLICATE of the edge pixel)
-  for (int i = tid; i < (NMS_TILE_H + 4) * 18; i += NMS_THREADS) {
-    const int r = i / 18, wc = i - r * 18;
-    const int gy = clampi(y0 - 2 + r, 0, h - 1);
-    const int gx = x0 - 4 + 4 * wc;
-    uint32_t v;
-    if (gx < 0) v = 0x01010101u * gray[(size_t)gy * w];
-    else if (gx >= w) v = 0x01010101u * gray[(size_t)gy * w + w - 1];
-    else v = *reinterpret_cast<const uint32_t*>(gray + (size_t)gy * w + gx);
-    s_gw[r][wc] = v;
-  }
-  __syncthreads();
-  // phase B: Sobel 3x3 + L2 magnitude, 4 adjacent positions per task from 9 word reads
-  for (int i = tid; i < (NMS_TILE_H + 2) * 18; i += NMS_THREADS) {
-    const int r = i / 18, c = i - r * 18;
-    const int iy = y0 - 1 + r;
-    // bytes bc = 4c-1 .. 4c+4 of gray rows r, r+1, r+2
-    uint32_t lo[3], mid[3], hi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = c > 0 ? s_gw[r + k][c - 1] : 0u;
-      mid[k] = s_gw[r + k][c];
-      hi[k] = c < 17 ? s_gw[r + k][c + 1] : 0u;
-    }
-    int mg[4], dq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // neighbours of byte j of `mid`: left = byte j-1 (or byte 3 of lo), right = byte j+1 (or byte 0 of hi)
-      int L3[3], C3[3], R3[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        L3[k] = j == 0 ? (int)(lo[k] >> 24) : (int)((mid[k] >> (8 * (j - 1))) & 255u);
-        C3[k] = (int)((mid[k] >> (8 * j)) & 255u);
-        R3[k] = j == 3 ? (int)(hi[k] & 255u) : (int)((mid[k] >> (8 * (j + 1))) & 255u);
-      }
-      const int dx = (R3[0] + 2 * R3[1] + R3[2]) - (L3[0] + 2 * L3[1] + L3[2]);
-      const int dy = (L3[2] + 2 * C3[2] + R3[2]) - (L3[0] + 2 * C3[0] + R3[0]);
-      const int ix = x0 - 4 + 4 * c + j;
-      const bool inside = ix >= 0 && ix < w && iy >= 0 && iy < h;
-      mg[j] = inside ? dx * dx + dy * dy : 0;
-      dq[j] = inside ? (int)(((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16)) : 0;
-    }
-    *reinterpret_cast<int4*>(&s_mag[r][4 * c]) = make_int4(mg[0], mg[1], mg[2], mg[3]);
-    *reinterpret_cast<int4*>(&s_dxy[r][4 * c]) = make_int4(dq[0], dq[1], dq[2], dq[3]);
-  }
-  __syncthreads();
+struct HRow { s2v d[5], s[5]; };  // column pairs (-1,0) (1,2) (3,4) (5,6) (7,8) relative to the thread's first pixel
 
-  // phase C: non-maximum suppression, 4 adjacent pixels per thread and pass (a pass = 16 tile rows)
+// prev = g[-4..-1], m0 = g[0..3], m1 = g[4..7], next = g[8..11]
+__device__ __forceinline__ HRow hrow(uint32_t prev, uint32_t m0, uint32_t m1, uint32_t next) {
+  // even pairs E_k = (g[2k-2], g[2k-1]), odd pairs O_k = (g[2k-1], g[2k])
+  const s2v E0 = PAIR(0u, prev, 0x0c030c02u), E1 = PAIR(0u, m0, 0x0c010c00u), E2 = PAIR(0u, m0, 0x0c030c02u);
+  const s2v E3 = PAIR(0u, m1, 0x0c010c00u), E4 = PAIR(0u, m1, 0x0c030c02u), E5 = PAIR(0u, next, 0x0c010c00u);
+  const s2v O0 = PAIR(m0, prev, 0x0c040c03u), O1 = PAIR(0u, m0, 0x0c020c01u), O2 = PAIR(m1, m0, 0x0c040c03u);
+  const s2v O3 = PAIR(0u, m1, 0x0c020c01u), O4 = PAIR(next, m1, 0x0c040c03u);
+  HRow r;
+  r.d[0] = E1 - E0; r.d[1] = E2 - E1; r.d[2] = E3 - E2; r.d[3] = E4 - E3; r.d[4] = E5 - E4;
+  r.s[0] = (E0 + E1) + (O0 + O0); r.s[1] = (E1 + E2) + (O1 + O1); r.s[2] = (E2 + E3) + (O2 + O2);
+  r.s[3] = (E3 + E4) + (O3 + O3); r.s[4] = (E4 + E5) + (O4 + O4);
+  return r;
+}
+
+struct MRow { int m[10]; uint32_t dxy[8]; };  // |grad|^2 of columns -1..8; (dx | dy << 16) of columns 0..7
+
+// Sobel of the row between a (above) and c (below), b the row itself; cm[]: column masks (0 outside the image)
+__device__ __forceinline__ MRow mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm) {
+  MRow r;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const s2v dx = (a.d[k] + c.d[k]) + (b.d[k] + b.d[k]);
+    const s2v dy = c.s[k] - a.s[k];
+    // column 2k-1: low halves, column 2k: high halves
+    const uint32_t lo = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x05040100u);
+    const uint32_t hi = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x07060302u);
+    r.m[2 * k] = __builtin_amdgcn_sdot2(as_s2(lo), as_s2(lo), 0, false);
+    r.m[2 * k + 1] = __builtin_amdgcn_sdot2(as_s2(hi), as_s2(hi), 0, false);
+    if (k > 0) r.dxy[2 * k - 1] = lo;
+    if (k < 4) r.dxy[2 * k] = hi;
+  }
+  // |grad|^2 outside the image is 0 (cv::Canny pads its magnitude buffer with zeros); columns 0..3 of an
+  // active thread are always inside
+  r.m[0] &= (int)cm[0];
+#pragma unroll
+  for (int k = 5; k < 10; ++k) r.m[k] &= (int)cm[k - 4];
+  return r;
+}
+__device__ __forceinline__ MRow zero_row() {
+  MRow r;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) r.m[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.dxy[k] = 0u;
+  return r;
+}
+
+// NMS of one row (cv::Canny): 8 candidate bits and 8 strong bits
+__device__ __forceinline__ void nms_row(const MRow& A, const MRow& B, const MRow& C, int low, int high, uint32_t* cand,
+                                        uint32_t* strong) {
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
-  const int lx0 = (tid % 16) * 4;
-  const int bc0 = lx0 + 4;  // byte column of the first pixel
-  int cand[NMS_PASSES][4];
+  uint32_t cb = 0, sb = 0;
 #pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
-    int mrow[3][6];  // magnitudes of rows ly, ly+1, ly+2 (mag-row coords), columns bc0-1 .. bc0+4
+  for (int k = 0; k < 8; ++k) {
+    const int i = k + 1;
+    const int m = B.m[i];
+    const uint32_t dxy = B.dxy[k];
+    const s2v v = as_s2(dxy);
+    const s2v z = {0, 0};
+    const uint32_t ab = as_u32(__builtin_elementwise_max(v, z - v));  // |dx| | |dy| << 16
+    const int ax = (int)(ab & 0xffffu);
+    const int ay15 = (int)((ab >> 1) & 0x7fff8000u);                  // |dy| << 15
+    const int t22 = ax * TG22;
+    const bool horiz = ay15 < t22;
+    const bool vert = ay15 > t22 + (ax << 16);
+    const bool neg = (int)(dxy ^ (dxy << 16)) < 0;                    // sign(dx) != sign(dy)
+    const int diag_a = neg ? A.m[i + 1] : A.m[i - 1];
+    const int diag_b = neg ? C.m[i - 1] : C.m[i + 1];
+    const int a = horiz ? B.m[i - 1] : (vert ? A.m[i] : diag_a);
+    const int b = horiz ? B.m[i + 1] : (vert ? C.m[i] : diag_b);
+    const bool ge = horiz || vert;                                    // m > a && m >= b on the axes, m > both on the diagonals
+    const bool is_max = (m > a) && (ge ? (m >= b) : (m > b));
+    const bool c = (m > low) && is_max;
+    cb |= c ? (1u << k) : 0u;
+    sb |= (c && m > high) ? (1u << k) : 0u;
+  }
+  *cand = cb;
+  *strong = sb;
+}
+
+#define NMS_R 6
+__global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
+  const int f = g.frame0 + blockIdx.z;
+  const int l = level_of(g, blockIdx.x, &LevelGeom::nms_block_base);
+  const LevelGeom& lv = g.lv[l];
+  const int w = lv.w, h = lv.h;
+  const int rt = 4 * lv.wpr;  // threads per row: a quad of threads makes one 32-pixel bitmap word
+  const int t = (blockIdx.x - lv.nms_block_base) * 256 + threadIdx.x;
+  const int yb = t / rt, xg = t - yb * rt;
+  const int y0 = yb * NMS_R;
+  if (y0 >= h) return;  // whole quads leave together (rt is a multiple of 4)
+  const int x = xg * 8;
+  const bool active = x < w;
+  const uint8_t* gray = pl.gray[l] + (size_t)f * lv.npix;
+  // word offsets inside a row (clamped, so every load is inside the row) and what to replicate at the border
+  const bool has_prev = x > 0, has_m1 = x + 4 < w, has_next = x + 8 < w;
+  const int xo = active ? x : 0;
+  const int o_prev = (active && has_prev) ? xo - 4 : xo, o_m1 = (active && has_m1) ? xo + 4 : xo, o_next = (active && has_next) ? xo + 8 : xo;
+  uint32_t cm[6];  // column masks of columns -1, 4, 5, 6, 7, 8
+  cm[0] = (active && has_prev) ? ~0u : 0u;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int4 m4 = *reinterpret_cast<const int4*>(&s_mag[ly + k][bc0]);
-      mrow[k][0] = s_mag[ly + k][bc0 - 1];
-      mrow[k][1] = m4.x; mrow[k][2] = m4.y; mrow[k][3] = m4.z; mrow[k][4] = m4.w;
-      mrow[k][5] = s_mag[ly + k][bc0 + 4];
+  for (int k = 1; k < 6; ++k) cm[k] = (active && x + 3 + k < w) ? ~0u : 0u;
+  auto load_hrow = [&](int r) -> HRow {
+    const int rr = clampi(r, 0, h - 1);  // BORDER_REPLICATE
+    const uint8_t* row = gray + (size_t)rr * w;
+    const uint32_t m0 = *reinterpret_cast<const uint32_t*>(row + xo);
+    uint32_t prev = *reinterpret_cast<const uint32_t*>(row + o_prev);
+    uint32_t m1 = *reinterpret_cast<const uint32_t*>(row + o_m1);
+    uint32_t next = *reinterpret_cast<const uint32_t*>(row + o_next);
+    if (!has_prev) prev = (m0 & 0xffu) * 0x01010101u;
+    if (!has_m1) m1 = (m0 >> 24) * 0x01010101u;
+    if (!has_next) next = (m1 >> 24) * 0x01010101u;
+    return hrow(prev, m0, m1, next);
+  };
+  auto mag_at = [&](int r, const HRow& a, const HRow& b, const HRow& c) -> MRow {
+    if (r < 0 || r >= h || !active) return zero_row();
+    return mag_row(a, b, c, cm);
+  };
+  HRow h0 = load_hrow(y0 - 2), h1 = load_hrow(y0 - 1), h2 = load_hrow(y0);
+  MRow A = mag_at(y0 - 1, h0, h1, h2);
+  h0 = load_hrow(y0 + 1);
+  MRow B = mag_at(y0, h1, h2, h0);
+  uint2* out = pl.cs[l] + ((size_t)f * h + y0) * lv.wpr + (xg >> 2);
+  const int sh = 8 * (threadIdx.x & 3);
+#pragma unroll
+  for (int i = 0; i < NMS_R; ++i) {
+    // rows of gray in flight: (h1, h2, h0) -> next (h2, h0, h1) -> ...: the unrolled loop renames, nothing moves
+    HRow hn = load_hrow(y0 + i + 2);
+    const HRow& ha = (i % 3 == 0) ? h2 : (i % 3 == 1 ? h0 : h1);
+    const HRow& hb = (i % 3 == 0) ? h0 : (i % 3 == 1 ? h1 : h2);
+    MRow Cm = mag_at(y0 + i + 1, ha, hb, hn);
+    uint32_t cb, sb;
+    nms_row(A, B, Cm, g.canny_low, g.canny_high, &cb, &sb);
+    // a quad's four bytes -> one word (DPP quad_perm: no LDS)
+    uint32_t cw = cb << sh, sw = sb << sh;
+    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0xB1, 0xf, 0xf, true);
+    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0x4E, 0xf, 0xf, true);
+    if ((threadIdx.x & 3) == 0 && y0 + i < h) out[(size_t)i * lv.wpr] = make_uint2(cw, sw);
+    if (i % 3 == 0) h1 = hn; else if (i % 3 == 1) h2 = hn; else h0 = hn;
+    A = B;
+    B = Cm;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a5 (second half): hysteresis.  cv::Canny keeps a candidate iff it is 8-connected, through
+// candidates, to a strong one.  One workgroup per (frame, level) holds the level's candidate bitmap C
+// and the growing edge bitmap E (seeded with the strong pixels) in LDS and iterates
+//      E <- E  u  fill_C( C n dilate8(E) )
+// to its fixpoint: every item (a column of 32-pixel words x a strip of rows) sweeps its strip down and
+// up, taking whole horizontal runs of C in one step with the carry trick
+//      fill = (((C + S) ^ C) & C) | S        (and its bit-reversed twin for the other direction),
+// so strong pixels -- the vast majority of an edge -- never need propagation and a weak chain costs one
+// iteration per strip / word it crosses.  Items read their neighbours' words while those are being
+// updated: E only ever grows and the operator is monotone, so any interleaving reaches the same
+// fixpoint; an iteration in which nothing changed proves it.  (Round 1: tile-local union-find in the NMS
+// kernel + three global pointer-chasing passes over a byte map and 4-byte labels: 162 us and ~450 MB per
+// 64-frame launch for these passes; this one reads and writes the level once.)
+// The same workgroup then writes edgesPyr (+ the edgesOrigPyr clone where fillInEdges may change the level,
+// imgpyramidrgbd.cpp:185-195) and generateDistHistogram's tile counts (imgpyramidrgbd.cpp:146-172; u8
+// counters wrap like the reference's ++ on uchar) straight from the bitmap.
+// ---------------------------------------------------------------------------
+#define HYST_THREADS 1024
+__device__ __forceinline__ uint32_t dil3(uint32_t a, uint32_t al, uint32_t ar) {
+  // a | a << 1 | a >> 1 with the neighbour words' edge bits shifted in
+  return a | __builtin_amdgcn_alignbit(a, al, 31) | __builtin_amdgcn_alignbit(ar, a, 1);
+}
+__device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S subset of C: the runs of C that hold a bit of S
+  const uint32_t up = ((C + S) ^ C) & C;
+  const uint32_t rC = __builtin_bitreverse32(C), rS = __builtin_bitreverse32(S);
+  const uint32_t dn = __builtin_bitreverse32(((rC + rS) ^ rC) & rC);
+  return up | dn | S;
+}
+
+template <bool C_IN_LDS>
+__global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl) {
+  extern __shared__ uint32_t s_mem[];
+  __shared__ int s_changed[3];
+  const int f = g.frame0 + blockIdx.z;
+  const int l = blockIdx.x;
+  const LevelGeom& lv = g.lv[l];
+  const int w = lv.w, h = lv.h, wpr = lv.wpr;
+  const int pitch = wpr + 2;                     // one zero word left and right, one zero row above and below
+  uint32_t* E = s_mem;                           // (h + 2) x pitch
+  uint32_t* Cl = s_mem + (size_t)(h + 2) * pitch;  // h x wpr (C_IN_LDS)
+  const uint2* cs = pl.cs[l] + (size_t)f * h * wpr;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (h + 2) * pitch; i += HYST_THREADS) E[i] = 0u;
+  if (tid < 3) s_changed[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < h * wpr; i += HYST_THREADS) {
+    const uint2 v = cs[i];
+    const int r = i / wpr, c = i - r * wpr;
+    E[(r + 1) * pitch + c + 1] = v.y;
+    if (C_IN_LDS) Cl[i] = v.x;
+  }
+  __syncthreads();
+  // strips of rpt rows: at most HYST_THREADS items, one per thread
+  const int max_strips = HYST_THREADS / wpr;  // wpr <= 64 (width <= 2048)
+  const int rpt = (h + max_strips - 1) / max_strips;
+  const int nstrips = (h + rpt - 1) / rpt;
+  const bool has_item = tid < nstrips * wpr;
+  const int c = tid % wpr, strip = tid / wpr;
+  const int r0 = strip * rpt, r1 = min(h, r0 + rpt) - 1;
+  for (int it = 0; it < 8192; ++it) {  // the bound only guards against a hang; the fixpoint ends the loop
+    bool changed = false;
+    if (has_item) {
+      uint32_t* Ec = E + pitch + c + 1;  // Ec[r * pitch] = E(r, c)
+      auto Cat = [&](int r) -> uint32_t { return C_IN_LDS ? Cl[r * wpr + c] : cs[r * wpr + c].x; };
+      // down
+      uint32_t prev_d = dil3(Ec[(r0 - 1) * pitch], Ec[(r0 - 1) * pitch - 1], Ec[(r0 - 1) * pitch + 1]);
+      for (int r = r0; r <= r1; ++r) {
+        const uint32_t cur = Ec[r * pitch], cl = Ec[r * pitch - 1], cr = Ec[r * pitch + 1];
+        const uint32_t nd = dil3(Ec[(r + 1) * pitch], Ec[(r + 1) * pitch - 1], Ec[(r + 1) * pitch + 1]);
+        const uint32_t Cw = Cat(r);
+        const uint32_t hz = __builtin_amdgcn_alignbit(cur, cl, 31) | __builtin_amdgcn_alignbit(cr, cur, 1);
+        const uint32_t F = run_fill(Cw, cur | (Cw & (prev_d | nd | hz)));
+        if (F != cur) { Ec[r * pitch] = F; changed = true; }
+        prev_d = dil3(F, cl, cr);
+      }
+      // up
+      prev_d = dil3(Ec[(r1 + 1) * pitch], Ec[(r1 + 1) * pitch - 1], Ec[(r1 + 1) * pitch + 1]);
+      for (int r = r1; r >= r0; --r) {
+        const uint32_t cur = Ec[r * pitch], cl = Ec[r * pitch - 1], cr = Ec[r * pitch + 1];
+        const uint32_t nd = dil3(Ec[(r - 1) * pitch], Ec[(r - 1) * pitch - 1], Ec[(r - 1) * pitch + 1]);
+        const uint32_t Cw = Cat(r);
+        const uint32_t hz = __builtin_amdgcn_alignbit(cur, cl, 31) | __builtin_amdgcn_alignbit(cr, cur, 1);
+        const uint32_t F = run_fill(Cw, cur | (Cw & (prev_d | nd | hz)));
+        if (F != cur) { Ec[r * pitch] = F; changed = true; }
+        prev_d = dil3(F, cl, cr);
+      }
     }
-    const int4 d4 = *reinterpret_cast<const int4*>(&s_dxy[ly + 1][bc0]);
-    const int dxy4[4] = {d4.x, d4.y, d4.z, d4.w};
+    // three flags in rotation: the one reset here is written again only after the NEXT barrier and was last
+    // read before THIS one
+    if (changed) s_changed[it % 3] = 1;
+    __syncthreads();
+    const bool any = s_changed[it % 3] != 0;
+    if (tid == 0) s_changed[(it + 2) % 3] = 0;
+    if (!any) break;
+  }
+  __syncthreads();
+  // edgesPyr / edgesOrigPyr: 16 pixels per store
+  uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
+  uint8_t* orig = lv.has_orig ? pl.edges_orig[l] + (size_t)f * lv.npix : nullptr;
+  for (int i = tid; i < lv.npix / 16; i += HYST_THREADS) {
+    const int p = i * 16;
+    const int y = p / w, x = p - y * w;  // w is a multiple of 4, npix of 16: a group may wrap into the next row
+    uint32_t o[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int lx = lx0 + k;
-      const int m = mrow[1][k + 1];
-      int val = 0;
-      if (m > g.canny_low) {
-        const int dxy = dxy4[k];
-        const int xs = (int)(int16_t)(dxy & 0xffff), ys = dxy >> 16;
-        const int ax = abs(xs), ay = abs(ys) << 15;
-        const int tg22x = ax * TG22;
-        bool is_max;
-        if (ay < tg22x) {
-          is_max = m > mrow[1][k] && m >= mrow[1][k + 2];
-        } else {
-          const int tg67x = tg22x + (ax << 16);
-          if (ay > tg67x) {
-            is_max = m > mrow[0][k + 1] && m >= mrow[2][k + 1];
-          } else {
-            const bool neg = (xs ^ ys) < 0;  // s = -1: up-right / down-left; s = +1: up-left / down-right
-            const int mu = neg ? mrow[0][k + 2] : mrow[0][k];
-            const int md = neg ? mrow[2][k] : mrow[2][k + 2];
-            is_max = m > mu && m > md;
+    for (int q = 0; q < 4; ++q) {
+      int xx = x + 4 * q, yy = y;
+      if (xx >= w) { xx -= w; yy += 1; }  // (w >= 16 is not guaranteed: at most one wrap per 4-pixel step is)
+      while (xx >= w) { xx -= w; yy += 1; }
+      const uint32_t bits = (E[(yy + 1) * pitch + (xx >> 5) + 1] >> (xx & 31)) & 0xfu;
+      o[q] = ((bits * 0x00204081u) & 0x01010101u) * 0xffu;
+    }
+    const uint4 v = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(edges + p) = v;
+    if (orig) *reinterpret_cast<uint4*>(orig + p) = v;
+  }
+  // histPyr[l] and the number of non-empty tiles (imgpyramidrgbd.cpp:146-172)
+  if (lv.patch > 0) {
+    const int ntiles = lv.hist_w * lv.hist_h;
+    int nz = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += HYST_THREADS) {
+      const int t = t0 + tid;
+      int cnt = 0;
+      if (t < ntiles) {
+        const int ty = t / lv.hist_w, tx = t - ty * lv.hist_w;
+        const int xa = tx * lv.patch, xb = xa + lv.patch;  // [xa, xb)
+        const int wa = xa >> 5, wb = (xb - 1) >> 5;
+        for (int y = ty * lv.patch; y < (ty + 1) * lv.patch; ++y) {
+          const uint32_t* row = E + (y + 1) * pitch + 1;
+          for (int ww = wa; ww <= wb; ++ww) {
+            uint32_t m = row[ww];
+            if (ww == wa) m &= ~0u << (xa & 31);
+            if (ww == wb && (xb & 31)) m &= ~0u >> (32 - (xb & 31));
+            cnt += __popc(m);
           }
         }
-        if (is_max) val = (m > g.canny_high) ? 2 : 1;
-      }
-      const bool inside = (x0 + lx < w) && (y0 + ly < h);
-      if (!inside) val = 0;
-      cand[ps][k] = val;
-    }
-    // Run-based initialisation: a row of the tile is handled by 16 consecutive lanes, so its 64-bit
-    // candidate mask is an OR-butterfly over those lanes; every candidate starts with the FIRST
-    // pixel of its horizontal run as parent.  Horizontal connectivity then needs no unions at all
-    // and the vertical links below produce chains bounded by the rows of the tile.
-    unsigned long long rm = (unsigned long long)((cand[ps][0] ? 1 : 0) | (cand[ps][1] ? 2 : 0) | (cand[ps][2] ? 4 : 0) |
-                                                 (cand[ps][3] ? 8 : 0)) << lx0;
-    rm |= __shfl_xor(rm, 1);
-    rm |= __shfl_xor(rm, 2);
-    rm |= __shfl_xor(rm, 4);
-    rm |= __shfl_xor(rm, 8);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = lx0 + k;
-      const unsigned long long zeros_below = ~rm & ((1ull << c) - 1ull);
-      const int start = zeros_below ? 64 - __clzll((long long)zeros_below) : 0;
-      s_lab[ly * NMS_TILE_W + c] = cand[ps][k] ? ly * NMS_TILE_W + start : -1;
-    }
-  }
-  __syncthreads();
-  // vertical links: N if it is a candidate (then NW / NE belong to N's run), otherwise NW and NE
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!cand[ps][k] || ly == 0) continue;
-      const int lx = lx0 + k;
-      const int me = ly * NMS_TILE_W + lx;
-      if (s_lab[me - NMS_TILE_W] >= 0) {
-        uf_unite(s_lab, me, me - NMS_TILE_W);
-      } else {
-        if (lx > 0 && s_lab[me - NMS_TILE_W - 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W - 1);
-        if (lx < NMS_TILE_W - 1 && s_lab[me - NMS_TILE_W + 1] >= 0) uf_unite(s_lab, me, me - NMS_TILE_W + 1);
+        const uint8_t v = (uint8_t)(cnt & 255);
+        pl.hist[l][(size_t)f * ntiles + t] = v;
+        nz += v != 0;
       }
     }
+    __shared__ int s_nz;  // block-wide sum of nz
+    if (tid == 0) s_nz = 0;
+    __syncthreads();
+    if (nz) atomicAdd(&s_nz, nz);
+    __syncthreads();
+    if (tid == 0) pl.hist_nz[f * REVO_L + l] = s_nz;
   }
-  __syncthreads();
-  // tile-local roots; a strong pixel marks its tile root (s_mag is free now: reused as flags)
-  int* s_strong = &s_mag[0][0];  // (NMS_TILE_H+2)*NMS_MS ints >= NMS_TILE_H*NMS_TILE_W
-  int root[NMS_PASSES][4];
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      root[ps][k] = cand[ps][k] ? uf_find(s_lab, ly * NMS_TILE_W + lx0 + k) : -1;
-      s_strong[ly * NMS_TILE_W + lx0 + k] = 0;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (cand[ps][k] == 2) s_strong[root[ps][k]] = 1;  // benign same-value race
-  __syncthreads();
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16;
-    if (x0 + lx0 < w && y0 + ly < h) {
-      const size_t pix = (size_t)(y0 + ly) * w + x0 + lx0;
-      uint32_t packed = 0;
-      int4 lab;
-      int* lp = &lab.x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        int key = -1;
-        uint32_t byte = (uint32_t)cand[ps][k];  // 0 none, 1 weak, 2 strong
-        if (cand[ps][k]) {
-          const int me = ly * NMS_TILE_W + lx0 + k;
-          const int r = root[ps][k];
-          key = (y0 + r / NMS_TILE_W) * w + x0 + (r % NMS_TILE_W);
-          if (r == me) byte |= 8u | (s_strong[me] ? 4u : 0u);  // bit 3: tile root, bit 2: its component holds a strong pixel
-        }
-        lp[k] = key;
-        packed |= byte << (8 * k);
-      }
-      *reinterpret_cast<uint32_t*>(pl.nms[l] + (size_t)f * lv.npix + pix) = packed;
-      // parents are only ever read for candidates (every consumer tests the map first): skipping the
-      // -1 fill of the ~92 % candidate-free groups saves most of the 4 B/px label traffic
-      if (packed) *reinterpret_cast<int4*>(pl.scratch[l] + (size_t)f * lv.npix + pix) = lab;
-    }
-  }
-}
-
-// The three global hysteresis passes handle 16 pixels per thread (one 16-byte load of the
-// map): with one byte per thread they were pure launch/latency overhead (26 M threads).
-// level = blockIdx.y (block-uniform, so the geometry is read with scalar loads); blocks past
-// the end of a small level exit at once.
-__device__ __forceinline__ bool ccl_chunk(const PyrGeom& g, int chunk, int* l_out, int* p0_out) {
-  const int l = blockIdx.y;
-  if (chunk * 16 >= g.lv[l].npix) return false;
-  *l_out = l;
-  *p0_out = chunk * 16;
-  return true;
-}
-
-// a5 (second half, 1/3): unite candidates across tile borders (global memory).  One block per
-// NMS tile, one thread per BORDER pixel of the tile (top row, left column, right column): the
-// unions of a horizontal edge lying on a tile's top row run in parallel instead of 48 in a row
-// inside one thread.
-__global__ void __launch_bounds__(64 + 2 * NMS_TILE_H) k_ccl_border(PyrGeom g, FramePlanes pl) {
-  const int f = g.frame0 + blockIdx.z;
-  const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
-  const LevelGeom& lv = g.lv[l];
-  const int t = blockIdx.x - lv.tile_base;
-  const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
-  const int w = lv.w, h = lv.h;
-  const int tid = threadIdx.x;
-  int lx, ly;
-  if (tid < 64) { lx = tid; ly = 0; }
-  else if (tid < 64 + NMS_TILE_H) { lx = 0; ly = tid - 64; }
-  else if (tid < 64 + 2 * NMS_TILE_H) { lx = NMS_TILE_W - 1; ly = tid - 64 - NMS_TILE_H; }
-  else return;
-  if (tid >= 64 && ly == 0) return;  // the corners belong to the top row
-  const int x = x0 + lx, y = y0 + ly;
-  if (x >= w || y >= h) return;
-  const uint8_t* nmsp = pl.nms[l] + (size_t)f * lv.npix;
-  const int p = y * w + x;
-  if ((nmsp[p] & 3) == 0) return;
-  int* L = pl.scratch[l] + (size_t)f * lv.npix;
-  // neighbours that live in another tile: the four map bytes are fetched together (they were four
-  // dependent round trips behind short-circuit conditions), then the unions run
-  const bool want_w = lx == 0 && x > 0;
-  const bool want_nw = y > 0 && (lx == 0 || ly == 0) && x > 0;
-  const bool want_n = y > 0 && ly == 0;
-  const bool want_ne = y > 0 && (lx == NMS_TILE_W - 1 || ly == 0) && x < w - 1;
-  const uint8_t b_w = want_w ? nmsp[p - 1] : (uint8_t)0;
-  const uint8_t b_nw = want_nw ? nmsp[p - w - 1] : (uint8_t)0;
-  const uint8_t b_n = want_n ? nmsp[p - w] : (uint8_t)0;
-  const uint8_t b_ne = want_ne ? nmsp[p - w + 1] : (uint8_t)0;
-  if (b_w & 3) uf_unite_global(L, p, p - 1);
-  if (b_nw & 3) uf_unite_global(L, p, p - w - 1);
-  if (b_n & 3) uf_unite_global(L, p, p - w);
-  if (b_ne & 3) uf_unite_global(L, p, p - w + 1);
-}
-
-// a5 (2/3): only TILE ROOTS (bit 3) work here: each is re-pointed straight at its global
-// root (so every pixel is <= 2 hops away afterwards) and hands its tile-level "holds a
-// strong pixel" bit to that root.
-__global__ void __launch_bounds__(256) k_ccl_flag(PyrGeom g, FramePlanes pl) {
-  const int f = g.frame0 + blockIdx.z;
-  int l, p0;
-  if (!ccl_chunk(g, blockIdx.x * 256 + threadIdx.x, &l, &p0)) return;
-  const LevelGeom& lv = g.lv[l];
-  uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
-  const uint4 m4 = *reinterpret_cast<const uint4*>(nms + p0);
-  if (((m4.x | m4.y | m4.z | m4.w) & 0x08080808u) == 0) return;
-  const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
-  int* L = pl.scratch[l] + (size_t)f * lv.npix;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const uint32_t b = (mw[k >> 2] >> (8 * (k & 3))) & 0xffu;
-    if (!(b & 8u)) continue;
-    const int p = p0 + k;
-    const int r = uf_find_final(L, p);
-    if (r != p) L[p] = r;  // any concurrent reader sees the old parent or the root: both are ancestors
-    if (b & 4u) nms[r] = (uint8_t)(nms[r] | 4u);  // every writer sets bit 2, the other bits are constant
-  }
-}
-
-// a5 (3/3): edge = candidate whose component holds a strong pixel.  Writes edgesPyr and its clone
-// edgesOrigPyr (imgpyramidrgbd.cpp:185-186).  One block per NMS tile, 4 pixels per thread (the
-// mapping of k_canny_nms).  All candidates of a tile-local component share one tile root, and after
-// k_ccl_flag a tile root points straight at its global root: so only the tile's ROOTS (a handful)
-// chase pointers -- two batched loads each -- and leave their verdict in LDS; every other candidate
-// reads the verdict of its tile root from LDS.  (Before: every candidate pixel chased two dependent
-// global loads on its own.)  A parent that path halving moved out of the tile, or onto a non-root,
-// takes the global walk.
-__global__ void __launch_bounds__(NMS_THREADS) k_ccl_out(PyrGeom g, FramePlanes pl) {
-  __shared__ uint32_t s_verdict[NMS_TILE_H * NMS_TILE_W / 4];  // bytes: 0xff unknown, 0 weak-only, 1 holds a strong pixel
-  const int f = g.frame0 + blockIdx.z;
-  const int l = level_of(g, blockIdx.x, &LevelGeom::tile_base);
-  const LevelGeom& lv = g.lv[l];
-  const int t = blockIdx.x - lv.tile_base;
-  const int x0 = (t % lv.tiles_x) * NMS_TILE_W, y0 = (t / lv.tiles_x) * NMS_TILE_H;
-  const int w = lv.w, h = lv.h;
-  const int tid = threadIdx.x;
-  uint8_t* verdict = reinterpret_cast<uint8_t*>(s_verdict);
-  const uint8_t* nms = pl.nms[l] + (size_t)f * lv.npix;
-  const int* L = pl.scratch[l] + (size_t)f * lv.npix;
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) s_verdict[ps * NMS_THREADS + tid] = 0xffffffffu;
-  uint32_t m[NMS_PASSES];
-  int p0[NMS_PASSES];
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
-    const bool inside = (x0 + lx0 < w) && (y0 + ly < h);  // w is a multiple of 4: a group is inside or outside as a whole
-    p0[ps] = (y0 + ly) * w + x0 + lx0;
-    m[ps] = inside ? *reinterpret_cast<const uint32_t*>(nms + p0[ps]) : 0u;
-  }
-  // the parents of this thread's 4 pixels (one coalesced int4, only where there is a candidate): for a
-  // tile root that IS its global root after k_ccl_flag, for the others their tile root -- fetched once,
-  // before the root phase, so that a block spends 3 dependent round trips (map, parents, root's map
-  // byte) instead of 5
-  int4 lab[NMS_PASSES];
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps)
-    lab[ps] = (m[ps] & 0x03030303u) ? *reinterpret_cast<const int4*>(L + p0[ps]) : make_int4(-1, -1, -1, -1);
-  __syncthreads();
-  // tile roots: the strong bit of their global root (batched over the 4 pixels of the thread)
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    if ((m[ps] & 0x08080808u) == 0) continue;
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
-    const int tl[4] = {lab[ps].x, lab[ps].y, lab[ps].z, lab[ps].w};
-    int r[4];
-    uint8_t fl[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = ((m[ps] >> (8 * k)) & 8u) ? tl[k] : -1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) fl[k] = r[k] >= 0 ? nms[r[k]] : (uint8_t)0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (r[k] >= 0) verdict[ly * NMS_TILE_W + lx0 + k] = (fl[k] & 4u) ? 1 : 0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int ps = 0; ps < NMS_PASSES; ++ps) {
-    const int ly = ps * NMS_ROWS_PER_PASS + tid / 16, lx0 = (tid % 16) * 4;
-    if (!((x0 + lx0 < w) && (y0 + ly < h))) continue;
-    uint32_t o = 0;
-    if (m[ps] & 0x03030303u) {
-      const int tl[4] = {lab[ps].x, lab[ps].y, lab[ps].z, lab[ps].w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t b = (m[ps] >> (8 * k)) & 0xffu;
-        if ((b & 3u) == 0) continue;
-        int v;
-        if (b & 8u) {
-          v = verdict[ly * NMS_TILE_W + lx0 + k];  // a tile root: its own verdict
-        } else {
-          const int py = tl[k] / w - y0, px = tl[k] % w - x0;
-          v = (py >= 0 && py < NMS_TILE_H && px >= 0 && px < NMS_TILE_W) ? verdict[py * NMS_TILE_W + px] : 0xff;
-        }
-        if (v == 0xff) {  // parent outside the tile or not a tile root (moved by path halving): walk
-          const int r = uf_find_final(L, tl[k]);
-          v = (nms[r] & 4) ? 1 : 0;
-        }
-        if (v) o |= 0xffu << (8 * k);
-      }
-    }
-    *reinterpret_cast<uint32_t*>(pl.edges[l] + (size_t)f * lv.npix + p0[ps]) = o;
-    *reinterpret_cast<uint32_t*>(pl.edges_orig[l] + (size_t)f * lv.npix + p0[ps]) = o;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// a6: generateDistHistogram (imgpyramidrgbd.cpp:146-172): one block per
-// (level, tile row); u8 counters wrap like the reference's ++ on uchar.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_hist(PyrGeom g, FramePlanes pl, int rows_total) {
-  __shared__ int s_cnt[128];
-  const int f = g.frame0 + blockIdx.z;
-  // decode (level, tile row) over the levels that have a histogram
-  int l = -1, ty = blockIdx.x;
-  for (int k = 0; k < g.n_levels; ++k) {
-    if (g.lv[k].patch <= 0) continue;
-    if (ty < g.lv[k].hist_h) { l = k; break; }
-    ty -= g.lv[k].hist_h;
-  }
-  if (l < 0) return;
-  const LevelGeom lv = g.lv[l];
-  const int tid = threadIdx.x;
-  if (tid < 128) s_cnt[tid] = 0;
-  __syncthreads();
-  const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
-  const int bw = lv.hist_w * lv.patch;
-  if ((bw % 16) == 0 && (lv.w % 16) == 0) {
-    const int chunks = bw / 16;
-    for (int i = tid; i < lv.patch * chunks; i += 256) {
-      const int y = ty * lv.patch + i / chunks, x0 = (i % chunks) * 16;
-      const uint4 v = *reinterpret_cast<const uint4*>(edges + (size_t)y * lv.w + x0);
-      if ((v.x | v.y | v.z | v.w) == 0) continue;
-      const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
-      // walk the 16 pixels once: the tile index advances at tile boundaries (one division per chunk, not
-      // per pixel) and a tile gets ONE LDS atomic with its count instead of one per edge pixel
-      int t = x0 / lv.patch, next = (t + 1) * lv.patch, c = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (x0 + k == next) {
-          if (c) atomicAdd(&s_cnt[t], c);
-          c = 0;
-          ++t;
-          next += lv.patch;
-        }
-        c += ((vw[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1 : 0;
-      }
-      if (c) atomicAdd(&s_cnt[t], c);
-    }
-  } else {
-    for (int i = tid; i < lv.patch * bw; i += 256) {
-      const int y = ty * lv.patch + i / bw, x = i % bw;
-      if (edges[(size_t)y * lv.w + x] > 0) atomicAdd(&s_cnt[x / lv.patch], 1);
-    }
-  }
-  __syncthreads();
-  int nz = 0;
-  if (tid < lv.hist_w) {
-    const uint8_t v = (uint8_t)(s_cnt[tid] & 255);
-    pl.hist[l][(size_t)f * lv.hist_w * lv.hist_h + (size_t)ty * lv.hist_w + tid] = v;
-    nz = v != 0;
-  }
-  const unsigned long long m = __ballot(nz);
-  if ((tid & 63) == 0 && m) atomicAdd(&pl.hist_nz[f * REVO_L + l], __popcll(m));
 }
 
 // a7: fillInEdges (imgpyramidrgbd.cpp:111-145, gate 188-195).  Level l reads
@@ -1087,24 +904,33 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
 }
 
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_canny_nms, dim3(g.total_tiles, 1, B), dim3(NMS_THREADS), 0, s, g, p);
+  hipLaunchKernelGGL(k_canny_nms, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
 }
 
-void launch_ccl(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  dim3 grid((g.lv[0].npix / 16 + 255) / 256, g.n_levels, B);
-  hipLaunchKernelGGL(k_ccl_border, dim3(g.total_tiles, 1, B), dim3(64 + 2 * NMS_TILE_H), 0, s, g, p);
-  hipLaunchKernelGGL(k_ccl_flag, grid, dim3(256), 0, s, g, p);
-  hipLaunchKernelGGL(k_ccl_out, dim3(g.total_tiles, 1, B), dim3(NMS_THREADS), 0, s, g, p);
+// hysteresis + edge planes + tile histograms: one workgroup per (level, frame)
+void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  size_t e_bytes = 0, ec_bytes = 0;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const size_t e = (size_t)(g.lv[l].h + 2) * (g.lv[l].wpr + 2) * 4, c = (size_t)g.lv[l].h * g.lv[l].wpr * 4;
+    e_bytes = e > e_bytes ? e : e_bytes;
+    ec_bytes = e + c > ec_bytes ? e + c : ec_bytes;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {  // more than the default 64 KB of dynamic LDS
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<true>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<false>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
+    attr_set = true;
+  }
+  if (ec_bytes <= REVO_HYST_LDS_MAX)
+    hipLaunchKernelGGL(k_hyst<true>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), ec_bytes, s, g, p);
+  else  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
+    hipLaunchKernelGGL(k_hyst<false>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), e_bytes, s, g, p);
 }
 
-void launch_hist_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  int rows = 0;
-  for (int l = 0; l < g.n_levels; ++l)
-    if (g.lv[l].patch > 0) rows += g.lv[l].hist_h;
-  if (rows == 0) return;
-  hipMemsetAsync(p.hist_nz + (size_t)g.frame0 * REVO_L, 0, sizeof(int) * REVO_L * B, s);
-  hipLaunchKernelGGL(k_hist, dim3(rows, 1, B), dim3(256), 0, s, g, p, rows);
-  if (g.use_edge_hist && g.n_levels > 1) hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p);
+void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  bool any = false;
+  for (int l = 1; l < g.n_levels; ++l) any = any || g.lv[l].has_orig;
+  if (any) hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p);
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {

@@ -5,71 +5,75 @@
 // (optimizer.cpp:235-311), calcErrorAndBuffers + calculateWarpUpdate
 // (optimizer.cpp:74-234) and LGS6 (LGSX.h:185-404).
 //
-// A CLUSTER of 512-thread workgroups per frame-pair (6 at batch 32 = 192 of the 256 CUs, 8 for a
-// single pair) runs every pyramid level and every Levenberg-Marquardt iteration on the
-// device: no host round trip between residual evaluations.  The members of a cluster
-// split the point list, all-gather their 32 partial sums through 8-byte {epoch,value}
-// granules (agent-scope relaxed atomics, the data is the flag; MI355X_MICROARCH.md
-// "handoff" rows) and then take the SAME decision redundantly, so one exchange per
-// evaluation suffices.  Blocks of one pair share blockIdx % 8 (same XCD, same L2).
-// The reference's two hot loops (A: warp/project/bilinear
-// gather/Huber, B: 6-vector Jacobian into the 6x6 system) are fused, so the 7
-// scratch buffers of optimizer.h:146-152 never exist: each thread keeps the 21
-// upper-triangle entries of J^T W J, the 6 of J^T W r, sum(w r^2), sum(r^2) and
-// the good count in registers, a 64-lane "reduce-scatter" butterfly folds the
-// 32 values of a wavefront with 32 shuffles (instead of 32 x 6), the 8
-// per-wave partials meet in LDS and are summed in double in a fixed order
-// (deterministic run to run), and wave 0 runs the damped 6x6 solve (row-parallel
-// across lanes), SE3 exp and the accept/reject logic, publishing the next pose through LDS.
-// The kernel is budgeted at 3 waves per SIMD worth of registers (146 VGPRs) so that the build
-// kernels of the next batch can be resident next to it (see TRACK_MAXP below).
+// A CLUSTER of 512-thread workgroups per frame-pair runs every pyramid level and every
+// Levenberg-Marquardt iteration on the device: no host round trip between residual
+// evaluations.  The members of a cluster split the point list, all-gather their partial sums
+// through 8-byte {epoch,value} granules (agent-scope relaxed atomics, the data is the flag;
+// MI355X_MICROARCH.md "handoff" rows) and then take the SAME decision redundantly, so one
+// exchange per pass suffices.  Blocks of one pair share blockIdx % 8 (same XCD, same L2).
 //
-// The gradient/DT float4 table of the reference (imgpyramidrgbd.cpp:255-276) is NOT
-// read here: the kernel samples the 4x smaller DT plane and forms the four
-// corner gradients 0.5*(dt[i-1]-dt[i+1]), 0.5*(dt[i-w]-dt[i+w]) on the fly -- the
-// same float operations, hence the same values -- which keeps 4 pairs per XCD inside
-// the 4 MB L2 (first measurements: the table version was gather-latency bound at
-// ~19 cycles/point/CU against ~1.2 cycles of ALU work).
+// The serial chain of the reference's LM loop is what bounds the kernel (a pass costs a few
+// microseconds of latency, not of arithmetic), so the chain is shortened, not just sped up:
+//   * SPECULATIVE CANDIDATES.  ~60 % of the reference's residual evaluations are rejected retries
+//     (optimizer.cpp:291-304: same normal equations, larger damping).  All retries of an outer
+//     iteration are known in advance from (A, b, lambda, incTry), so one pass evaluates candidate 0
+//     in full (residual + Jacobian + normal equations, optimizer.cpp:74-234 fused) and the next
+//     KSPEC-1 retries error-only (4 DT samples instead of 12, no Jacobian).  The decision then
+//     consumes the results in the reference's order: 43 passes per pair become ~27, the pose and
+//     the evaluation counts are those of the reference's sequence.
+//   * The init check (tracker.cpp:265-283) evaluates both costs in one pass.
+//   * The damped 6x6 solves + SE3 exp of the KSPEC candidates run on KSPEC wavefronts at once.
+//   * Levels with few points are evaluated by every member redundantly (identical bits), which
+//     removes the cluster exchange from their passes.
 //
-// There is no dense contraction here (a 6-vector outer product per point), so
-// no MFMA; the kernel is bound by the serial latency of one residual evaluation
-// (6.6 us: loop 47 %, LM decision 30 %, cluster exchange 13 %) times the ~40 evaluations of a pair.
+// The reference's two hot loops (A: warp/project/bilinear gather/Huber, B: 6-vector Jacobian into
+// the 6x6 system) are fused, so the 7 scratch buffers of optimizer.h:146-152 never exist: each
+// thread keeps the 21 upper-triangle entries of J^T W J, the 6 of J^T W r and per candidate
+// sum(w r^2), sum(r^2) and the good count in registers; 64-lane "reduce-scatter" butterflies fold
+// them, the per-wave partials meet in LDS and are summed in double in a fixed order
+// (deterministic run to run).
+//
+// The solve is Eigen's LDLT<Matrix6f> restated (optimizer.cpp:262): float, pivoted on the largest
+// |diagonal|, left-looking, pseudo-inverse of D -- row-parallel across lanes, every element seeing the
+// serial algorithm's operations in the serial order.
+//
+// The gradient/DT float4 table of the reference (imgpyramidrgbd.cpp:255-276) is NOT read here: the
+// kernel samples the 4x smaller DT plane and forms the corner gradients 0.5*(dt[i-1]-dt[i+1]),
+// 0.5*(dt[i-w]-dt[i+w]) on the fly -- the same float operations, hence the same values.
+//
+// There is no dense contraction here (a 6-vector outer product per point), so no MFMA.
 #include "revo_dev.h"
 
 namespace {
 
 enum { MODE_EVAL = 0, MODE_COST = 1, MODE_DONE = 2 };
-enum { PH_COST_EYE = 0, PH_COST_INIT = 1, PH_LEVEL_FIRST = 2, PH_LM = 3, PH_EVAL_ONLY = 4 };
+enum { PH_FIRST = 0, PH_LM = 1, PH_REFILL = 2, PH_EVAL_ONLY = 3 };
 #define NWAVES (TRACK_THREADS / 64)
+#define KMAX TRACK_KMAX
+#define NVAL TRACK_NVAL          // 32 normal-equation slots (27 used) + 16 error slots (3 per candidate)
+#define ESLOT 32
 #define SPIN_LIMIT 400000      // bounded cluster wait (~0.5 s): never hang the GPU
 #define MAX_TOTAL_EVALS 6000  // hang guard; the reference bound is 100 outer iterations x retries
+static_assert(3 * KMAX <= 16, "error slots: 3 per candidate");
 
-struct Ctrl {  // published by wave 0, read by everyone after the barrier
-  float R[9];
-  float T[3];
-  int level;
-  int mode;
+struct Cand {  // one pose to evaluate; for LM candidates also what the decision needs when it is consumed
+  float R[9], T[3];
+  float q[4], t[3];    // Sophus::SE3f new_referenceToFrame (optimizer.cpp:266)
+  float incsq, lambda; // inc.dot(inc) and the damping this candidate was solved with
+  int incTry;          // incTry after its increment (optimizer.cpp:263)
 };
-
-struct W0State {  // wave-0 private LM state, kept in LDS to keep VGPRs for the hot loop
-  double Aacc[27];  // accepted normal equations: 21 upper-tri of A/n, then 6 of (sum w r v)/n
+struct PassCtl { int mode, level, ncand, phase; };
+struct LMState {
   float q[4], t[3];    // accepted pose (Sophus::SE3f referenceToFrame)
-  float qn[4], tn[3];  // candidate pose
-  float lastErr, last_residual, lambda, incsq, costEye;
-  int iteration, incTry, phase, flags, total_evals;
-  int good, bad;
+  float lastErr, last_residual, lambda;
+  int iteration, incTry, flags, total_evals, good, bad;
   float sumw, sumu;
-  int evals[REVO_L];
-#ifdef REVO_TRACK_PROFILE
-  long long prof[6];  // cycles: eval loop, barrier 1, LDS sum, cluster exchange, decision, barrier 2
-#endif
 };
 
 // ---- small algebra (Eigen/Sophus semantics, float like the reference) -------
 // Eigen's Quaternionf(Matrix3f): four algebraically equivalent branches chosen by the
 // largest of (trace, m00, m11, m22).  Written branch-free with selects so the quaternion
-// stays in registers (element writes under control flow sent it to scratch memory, i.e. a
-// dozen vector-memory round trips on the serial path of every evaluation).
+// stays in registers.
 __device__ __forceinline__ void quat_from_R(const float* R, float* q) {  // R column-major; q = (w,x,y,z)
 #define RM(r, c) R[(c)*3 + (r)]
   const float m00 = RM(0, 0), m11 = RM(1, 1), m22 = RM(2, 2);
@@ -122,14 +126,15 @@ __device__ __forceinline__ bool is_orthogonal(const float* R) {  // rotation_mat
 
 // sin / cos for the LM increments (|x| is ~1e-2 .. 1e-1): below 0.5 rad the truncated series are
 // accurate to float rounding (next terms x^11/11! < 2e-11, x^10/10! < 3e-10 relative) and avoid the
-// full-range argument reduction of sinf/cosf on the serial path; larger angles take the library path.
+// full-range argument reduction of sinf/cosf on the serial path (and its ~150 instructions per call site in
+// the instruction cache); an increment beyond 0.5 rad only occurs when the LM diverges.
 __device__ __forceinline__ float sin_lm(float x) {
-  if (fabsf(x) > 0.5f) return sinf(x);
+  if (fabsf(x) > 0.5f) return __sinf(x);  // a diverging step: the hardware sine (|err| ~1e-6) keeps the code small
   const float x2 = x * x;
   return x * (1.0f + x2 * (-1.0f / 6.0f + x2 * (1.0f / 120.0f + x2 * (-1.0f / 5040.0f + x2 * (1.0f / 362880.0f)))));
 }
 __device__ __forceinline__ float cos_lm(float x) {
-  if (fabsf(x) > 0.5f) return cosf(x);
+  if (fabsf(x) > 0.5f) return __cosf(x);
   const float x2 = x * x;
   return 1.0f + x2 * (-0.5f + x2 * (1.0f / 24.0f + x2 * (-1.0f / 720.0f + x2 * (1.0f / 40320.0f))));
 }
@@ -208,70 +213,131 @@ __device__ __forceinline__ double powi_dd(double b, int n) {
   }
   return hi + lo;
 }
-
-// Damped 6x6 solve A(1+lambda on the diagonal) x = b in double (LDL^T, no
-// pivoting: A = J^T W J / n is positive semi-definite).  The reference solves
-// the same system with Eigen's float LDLT (optimizer.cpp:258-262); a zero /
-// invalid pivot contributes 0 like Eigen's pseudo-inverse of D.
-// Aacc: 21 upper-triangle entries (row-major) then 6 rhs.
-#define AIDX(i, j) ((i) * 6 - ((i) * ((i)-1)) / 2 + ((j) - (i)))  // upper triangle, i <= j
-__device__ __forceinline__ double bcast_lane(double v, int src) {  // wave-uniform copy of lane src's value (v_readlane)
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
+// LM_lambda after a rejected candidate (optimizer.cpp:300-303)
+__device__ __forceinline__ float lambda_after_reject(float lambda, float fail_fac, int incTry) {
+  if (lambda == 0.0f) return 0.2f;
+  if (fail_fac == 2.0f) return ldexpf(lambda, incTry);  // (float)((double)lambda * 2^incTry), exactly (the default factor)
+  return (float)((double)lambda * powi_dd((double)fail_fac, incTry));
 }
-// Row-parallel form: lane i (< 6) owns row i of A and of L; the pivots and the row-j entries a
-// step needs are broadcast with v_readlane.  Every element sees exactly the operations of the
-// textbook serial loops, in the same order (k ascending), so the result is bit-identical to
-// them -- but the serial chain is 6 steps instead of 21 and a lane keeps 12 doubles instead of 33.
-// Must be called by all 64 lanes of a wave (lanes >= 6 shadow row 5); x is wave-uniform.
-__device__ __forceinline__ void solve6(const double* Aacc, float lambda, float* x, int lane) {
-  const double damp = (double)(1.0f + lambda);
-  const int row = lane < 6 ? lane : 5;
-  double Arow[6], Lrow[6];
+
+// ---- Eigen LDLT<Matrix6f>::compute + solve (optimizer.cpp:262), float -------------------------
+// ldlt_inplace<Lower>::unblocked pivots on the largest |diagonal| of the ORIGINAL diagonal entries (it is
+// left-looking: a diagonal entry is only updated in the step that eliminates it), so the transposition
+// sequence is known up front and the factorisation is an unpivoted left-looking LDL^T of P A P^T.
+#define AIDX(i, j) ((i) * 6 - ((i) * ((i)-1)) / 2 + ((j) - (i)))  // upper triangle, i <= j
+__device__ __forceinline__ float rl(float v, int src) {  // wave-uniform copy of lane src's value (v_readlane)
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src));
+}
+// abv: lane k (< 27) of the calling wave holds entry k of the normalised normal equations (21 upper-triangle
+// entries of A, then 6 of the rhs).  Must be called by all 64 lanes of a wave (lanes >= 6 shadow row 5); x is
+// wave-uniform.
+__device__ __forceinline__ void solve6_ldlt(float abv, float lambda, float* x, int lane) {
+  const float damp = 1.0f + lambda;  // A(i,i) *= 1 + LM_lambda, optimizer.cpp:261
+  // transpositions on the damped diagonal: big = first maximum of |diag| among positions >= k
+  float dv[6];
+  int idx[6];  // idx[i] = original row/column at position i of P A P^T
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    const int lo = row < c ? row : c, hi = row < c ? c : row;
-    Arow[c] = Aacc[AIDX(lo, hi)];
-    Lrow[c] = 0.0;
-  }
-  double v = Aacc[21 + row];  // rhs of this row, becomes y then x
-  double D[6], Dinv_mine = 0.0;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double a = (row == j) ? Arow[j] * damp : Arow[j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) a -= Lrow[k] * bcast_lane(Lrow[k], j) * D[k];
-    const double dj = bcast_lane(a, j);
-    D[j] = dj;
-    const double dinv = (dj > 1e-300) ? 1.0 / dj : 0.0;
-    if (row == j) Dinv_mine = dinv;
-    if (row > j) Lrow[j] = a * dinv;
-  }
-  // forward substitution L y = b (k ascending per row), then y *= D^-1
+  for (int i = 0; i < 6; ++i) { dv[i] = fabsf(rl(abv, AIDX(i, i)) * damp); idx[i] = i; }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
-    const double yk = bcast_lane(v, k);
-    if (row > k) v -= Lrow[k] * yk;
+    int big = k;
+    float bigv = dv[k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+      if (dv[i] > bigv) { bigv = dv[i]; big = i; }
+    // swap positions k and big (static positions, wave-uniform selects)
+    const float dk = dv[k];
+    const int ik = idx[k];
+    int ib = ik;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+      if (i == big) { ib = idx[i]; idx[i] = ik; dv[i] = dk; }
+    idx[k] = ib;
+    dv[k] = bigv;
   }
-  v *= Dinv_mine;
-  // backward substitution L^T x = y: x_i = y_i - sum_{k>i} L[k][i] x_k, k ascending
-  double xs[6];
+  // row `row` of the permuted, damped matrix (lower triangle is what the algorithm touches)
+  const int row = lane < 6 ? lane : 5;
+  int myorig = idx[0];
+#pragma unroll
+  for (int i = 1; i < 6; ++i) myorig = (row == i) ? idx[i] : myorig;
+  float m[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int oc = idx[c];
+    const int lo = myorig < oc ? myorig : oc, hi = myorig < oc ? oc : myorig;
+    float v = __shfl(abv, AIDX(lo, hi));
+    if (lo == hi) v = v * damp;
+    m[c] = v;
+  }
+  float v = __shfl(abv, 21 + myorig);  // m_transpositions * rhs
+  float D[6];
+  bool stop = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k > 0 && !stop) {
+      float a2 = 0.0f;
+#pragma unroll
+      for (int c = 0; c < k; ++c) {
+        const float tc = D[c] * rl(m[c], k);  // temp = D(0..k) .* A10^T
+        a2 = a2 + m[c] * tc;
+      }
+      if (row >= k) m[k] = m[k] - a2;         // A(k,k) -= A10 temp ; A21 -= A20 temp
+    }
+    const float akk = rl(m[k], k);
+    D[k] = akk;
+    const bool valid = fabsf(akk) > 0.0f;
+    if (k == 0 && !valid) stop = true;        // the whole diagonal is zero: Eigen leaves the matrix as it is
+    if (!stop && valid && row > k) m[k] = __fdiv_rn(m[k], akk);
+  }
+  // L y = P b (j ascending per row)
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float yj = rl(v, j);
+    if (row > j) v = v - m[j] * yj;
+  }
+  // pseudo-inverse of D (tolerance = 1 / highest())
+  float mydiag = D[0];
+#pragma unroll
+  for (int i = 1; i < 6; ++i) mydiag = (row == i) ? D[i] : mydiag;
+  v = (fabsf(mydiag) > 1.17549435e-38f) ? __fdiv_rn(v, mydiag) : 0.0f;
+  // L^T z = y: z_i = y_i - sum_{j>i} L[j][i] z_j, j ascending
+  float zs[6];
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
-    const double term = Lrow[i] * v;  // lane k > i: L[k][i] * x_k (x_k is final on those lanes)
-    double acc = bcast_lane(v, i);
+    const float term = m[i] * v;  // lane j > i: L[j][i] * z_j (z_j is final on those lanes)
+    float acc = rl(v, i);
 #pragma unroll
-    for (int k = i + 1; k < 6; ++k) acc -= bcast_lane(term, k);
-    xs[i] = acc;
+    for (int j = i + 1; j < 6; ++j) acc = acc - rl(term, j);
+    zs[i] = acc;
     if (row == i) v = acc;
   }
+  // P^T z
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
+  for (int o = 0; o < 6; ++o) {
+    float xo = zs[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) xo = (idx[i] == o) ? zs[i] : xo;
+    x[o] = xo;
+  }
 }
 
-// 64-lane reduce-scatter butterfly: 32 per-lane values -> lane L ends with the
-// wave total of value (L >> 1).  32 shuffles instead of 32 x 6.
+// ---- wave-level reduce-scatter ---------------------------------------------------------------
+// V per-lane values -> every value's wave total.  The halving steps exchange with lane ^ MASK; the masks
+// inside a 16-lane row are DPP lane permutations fused into VALU moves (no LDS crossbar, a few cycles), and
+// they come FIRST, when there are many values; only the last one or two values cross rows (ds_bpermute).
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int s = (int)__float_as_uint(v);
+  int r;
+  if (MASK == 1) r = __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+  else if (MASK == 2) r = __builtin_amdgcn_update_dpp(0, s, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  else if (MASK == 4) {
+    r = __builtin_amdgcn_update_dpp(0, s, 0x104, 0xf, 0x5, false);                   // row_shl:4 into banks 0, 2 (lane bit 2 clear)
+    r = __builtin_amdgcn_update_dpp(r, s, 0x114, 0xf, 0xa, false);                   // row_shr:4 into banks 1, 3
+  } else if (MASK == 8) r = __builtin_amdgcn_update_dpp(0, s, 0x128, 0xf, 0xf, true);  // row_ror:8
+  else return __shfl_xor(v, MASK);
+  return __uint_as_float((unsigned)r);
+}
 template <int HALF, int MASK>
 __device__ __forceinline__ void butterfly_step(float* v, int lane) {
   const bool up = (lane & MASK) != 0;
@@ -279,32 +345,59 @@ __device__ __forceinline__ void butterfly_step(float* v, int lane) {
   for (int i = 0; i < HALF; ++i) {
     const float send = up ? v[i] : v[HALF + i];
     const float keep = up ? v[HALF + i] : v[i];
-    v[i] = keep + __shfl_xor(send, MASK);
+    v[i] = keep + lane_xor<MASK>(send);
   }
 }
+// 32 values: lane L ends with the wave total of value idx32(L) in v[0]
+__device__ __forceinline__ void reduce32(float* v, int lane) {
+  butterfly_step<16, 1>(v, lane);
+  butterfly_step<8, 2>(v, lane);
+  butterfly_step<4, 4>(v, lane);
+  butterfly_step<2, 8>(v, lane);
+  butterfly_step<1, 16>(v, lane);
+  v[0] += lane_xor<32>(v[0]);
+}
+__device__ __forceinline__ int idx32(int lane) {
+  return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+}
+// 16 values: lane L ends with the wave total of value idx16(L) in v[0]
+__device__ __forceinline__ void reduce16(float* v, int lane) {
+  butterfly_step<8, 1>(v, lane);
+  butterfly_step<4, 2>(v, lane);
+  butterfly_step<2, 4>(v, lane);
+  butterfly_step<1, 8>(v, lane);
+  v[0] += lane_xor<16>(v[0]);
+  v[0] += lane_xor<32>(v[0]);
+}
+__device__ __forceinline__ int idx16(int lane) {
+  return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+}
 
-// ---- cluster all-gather of the 32 per-workgroup partials -------------------------
+// ---- cluster all-gather of the NVAL per-workgroup partials -------------------------
 typedef unsigned long long u64;
-// mail layout per pair: [2 (epoch parity)][cluster][32] granules of {epoch<<32 | float bits}
-__device__ __forceinline__ bool cluster_allgather(u64* __restrict__ mail_pair, int cluster, int member, unsigned epoch,
-                                                  float mine, int lane, double* tot_out) {
-  u64* slot = mail_pair + (size_t)(epoch & 1u) * cluster * 32;
-  if (lane < 32)
-    __hip_atomic_store(&slot[member * 32 + lane], ((u64)epoch << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED,
+// mail layout per pair: [2 (epoch parity)][cluster][NVAL] granules of {epoch<<32 | float bits}
+__device__ __forceinline__ void cluster_publish(u64* __restrict__ mail_pair, int cluster, int member, unsigned epoch, float mine,
+                                                int lane) {
+  u64* slot = mail_pair + (size_t)(epoch & 1u) * cluster * NVAL;
+  if (lane < NVAL)
+    __hip_atomic_store(&slot[member * NVAL + lane], ((u64)epoch << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+// every member granule in flight at once (a rolled loop would wait for each load before issuing the next:
+// `cluster` serial L2 round trips per poll); MAXC bounds the unrolled sweep
+template <int MAXC>
+__device__ __forceinline__ bool cluster_poll(const u64* __restrict__ slot, int cluster, unsigned epoch, int lane, double* tot_out) {
   double tot = 0.0;
   for (unsigned spins = 0;; ++spins) {
     bool all = true;
     tot = 0.0;
-    if (lane < 32) {
-      // all member granules in flight at once (a rolled loop over `cluster` waited for every load before
-      // issuing the next: 8 serial L2 round trips per poll, the exchange cost grew linearly with the cluster)
-      u64 g[TRACK_MAX_CLUSTER];
+    if (lane < NVAL) {
+      u64 g[MAXC];
 #pragma unroll
-      for (int j = 0; j < TRACK_MAX_CLUSTER; ++j)
-        g[j] = (j < cluster) ? __hip_atomic_load(&slot[j * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      for (int j = 0; j < MAXC; ++j)
+        g[j] = (j < cluster) ? __hip_atomic_load(&slot[j * NVAL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
-      for (int j = 0; j < TRACK_MAX_CLUSTER; ++j) {
+      for (int j = 0; j < MAXC; ++j) {
         if (j < cluster) {
           all = all && ((unsigned)(g[j] >> 32) == epoch);
           tot += (double)__uint_as_float((unsigned)g[j]);  // fixed order j = 0..cluster-1: same bits in every member
@@ -318,6 +411,13 @@ __device__ __forceinline__ bool cluster_allgather(u64* __restrict__ mail_pair, i
   *tot_out = tot;
   return true;
 }
+__device__ __forceinline__ bool cluster_gather(const u64* __restrict__ mail_pair, int cluster, unsigned epoch, int lane,
+                                               double* tot_out) {
+  const u64* slot = mail_pair + (size_t)(epoch & 1u) * cluster * NVAL;
+  if (cluster <= 8) return cluster_poll<8>(slot, cluster, epoch, lane, tot_out);
+  if (cluster <= 16) return cluster_poll<16>(slot, cluster, epoch, lane, tot_out);
+  return cluster_poll<TRACK_MAX_CLUSTER>(slot, cluster, epoch, lane, tot_out);
+}
 
 // explicit global address space: the pointers come out of the descriptor (generic), and
 // flat loads would tie up both vmcnt and lgkmcnt
@@ -327,9 +427,8 @@ typedef const f4v __attribute__((address_space(1)))* gf4p;
 
 // 12 DT samples around (ix,iy): rows iy-1 (2), iy (4), iy+1 (4), iy+2 (2)
 struct DtPatch { float a0, a1, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1; };
-template <typename PTR>
-__device__ __forceinline__ DtPatch load_patch(PTR dt, int w, int ix, int iy) {
-  PTR p = dt + iy * w + ix;
+__device__ __forceinline__ DtPatch load_patch(gf32p dt, int w, int ix, int iy) {
+  gf32p p = dt + iy * w + ix;
   DtPatch q;
   q.a0 = p[-w]; q.a1 = p[-w + 1];
   q.b0 = p[-1]; q.b1 = p[0]; q.b2 = p[1]; q.b3 = p[2];
@@ -339,16 +438,16 @@ __device__ __forceinline__ DtPatch load_patch(PTR dt, int w, int ix, int iy) {
 }
 
 struct PtState { float X, Y, Z, dx, dy; int ix, iy; bool valid; };
+struct Cam { float fx, fy, cx, cy, wlim, hlim; int w, h; };
 
-__device__ __forceinline__ PtState project_point(const f4v p, const float* R, const float* T, float fx, float fy, float cx,
-                                                 float cy, float wlim, float hlim, bool in_range) {
+__device__ __forceinline__ PtState project_point(const f4v p, const float* R, const float* T, const Cam& c, bool in_range) {
   PtState s;
   s.X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
   s.Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
   s.Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
-  const float u = __fdiv_rn(s.X, s.Z) * fx + cx;
-  const float v = __fdiv_rn(s.Y, s.Z) * fy + cy;
-  s.valid = in_range && (u > 1.0f && v > 1.0f && u < wlim && v < hlim);  // optimizer.cpp:100 (NaN-safe form)
+  const float u = __fdiv_rn(s.X, s.Z) * c.fx + c.cx;
+  const float v = __fdiv_rn(s.Y, s.Z) * c.fy + c.cy;
+  s.valid = in_range && (u > 1.0f && v > 1.0f && u < c.wlim && v < c.hlim);  // optimizer.cpp:100 (NaN-safe form)
   s.ix = s.valid ? (int)u : 1;
   s.iy = s.valid ? (int)v : 1;
   s.dx = u - (float)s.ix;
@@ -357,10 +456,19 @@ __device__ __forceinline__ PtState project_point(const f4v p, const float* R, co
   return s;
 }
 
+// the candidate's error terms: sum w r^2 (fma), sum r^2, good count -- identical arithmetic in the full and the
+// error-only evaluation, so a pose has ONE error whichever way it was evaluated
+__device__ __forceinline__ void accumulate_error(float res, float wr, bool good, float* e) {
+  const float r2 = res * res;
+  e[0] = fmaf(wr, r2, e[0]);
+  e[1] += r2;
+  e[2] += good ? 1.0f : 0.0f;
+}
+
 // calcErrorAndBuffers' interpolation + filter + Huber (optimizer.cpp:106-133, optimizer.h:156-185)
 // fused with calculateWarpUpdate's Jacobian (optimizer.cpp:218-228) and LGS6::update.
 __device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch& q, float fx, float fy, float ed, bool filt,
-                                                 float huber, float* acc) {
+                                                 float huber, float* acc, float* e) {
   // the reference's table entries at the four corners: (0.5(prev-next), 0.5(up-down), dt)
   const float gx00 = 0.5f * (q.b0 - q.b2), gy00 = 0.5f * (q.a0 - q.c1), d00 = q.b1;
   const float gx10 = 0.5f * (q.b1 - q.b3), gy10 = 0.5f * (q.a1 - q.c2), d10 = q.b2;
@@ -396,93 +504,86 @@ __device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) acc[21 + a] = fmaf(wv[a], res, acc[21 + a]);
-  const float r2 = res * res;
-  acc[27] = fmaf(wr, r2, acc[27]);
-  acc[28] += r2;
-  acc[29] += good ? 1.0f : 0.0f;
+  accumulate_error(res, wr, good, e);
+}
+
+__device__ __forceinline__ void full_point(const f4v p, gf32p dtm, const float* R, const float* T, const Cam& c, float ed,
+                                           bool filt, float huber, float* acc, float* e) {
+  const PtState s = project_point(p, R, T, c, true);
+  const DtPatch q = load_patch(dtm, c.w, s.ix, s.iy);
+  accumulate_point(s, q, c.fx, c.fy, ed, filt, huber, acc, e);
+}
+
+// TrackerNew::evalCostFunction's per-point term, tracker.cpp:371-389
+__device__ __forceinline__ float cost_point(const f4v p, gf32p dtm, const float* R, const float* T, const Cam& c, float ed,
+                                            bool filt) {
+  const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
+  const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
+  const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
+  const float u = __fdiv_rn(c.fx * X, Z) + c.cx;
+  const float v = __fdiv_rn(c.fy * Y, Z) + c.cy;
+  float cost = 0.0f;
+  if (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) {
+    const float r = dtm[(int)floorf(v) * c.w + (int)floorf(u)];
+    if (!(r > ed && filt)) cost = r;
+  }
+  return cost;
 }
 
 // Register budget.  k_track shares every CU with the pyramid-build kernels of the next batch
-// (bench.py / revo_batch_*: build k+1 overlaps track k).  With the compiler's default budget for a
-// 512-thread block (256 VGPRs) the kernel took 246, i.e. 2 waves x 246 = 96 % of each SIMD's
-// register file: a 32-VGPR k_canny_nms wave could not become resident next to it and the build
-// ran 2.3x slower while a tracker was in flight (profiles/r01_overlap_*.txt).  168 VGPRs (the
-// 3-waves-per-SIMD budget) is reached without spills once the points kept in registers are cut to
-// 4 per thread, the 6x6 solve is row-parallel and pow() is an integer power; that leaves 176
-// VGPRs per SIMD to the co-runners.  (128 needs spills on the decision path: slower overall.)
+// (bench.py / revo_batch_*: build k+1 overlaps track k): 168 VGPRs (the 3-waves-per-SIMD budget)
+// leaves 176 VGPRs per SIMD to the co-runners (profiles/r01_overlap_vgpr_study.txt).
 #ifndef TRACK_MAXP
-#define TRACK_MAXP 4                  // points of a level kept in registers per thread; the rest streams from L2
+#define TRACK_MAXP 2                  // points of a level kept in registers per thread; the rest streams from L2
 #endif
 #ifndef TRACK_WAVES_PER_EU
 #define TRACK_WAVES_PER_EU 3
 #endif
 
-// Two points in flight: both projections, then all 24 DT gathers, then the math.
-template <typename PTR>
-__device__ __forceinline__ void eval_pair(const f4v p0, const f4v p1, bool has0, bool has1, PTR dtm, int w, const float* R,
-                                          const float* T, float fx, float fy, float cx, float cy, float wlim, float hlim,
-                                          float ed, bool filt, float huber, float* acc) {
-  const PtState s0 = project_point(p0, R, T, fx, fy, cx, cy, wlim, hlim, has0);
-  const PtState s1 = project_point(p1, R, T, fx, fy, cx, cy, wlim, hlim, has1);
-  const DtPatch q0 = load_patch(dtm, w, s0.ix, s0.iy);
-  const DtPatch q1 = load_patch(dtm, w, s1.ix, s1.iy);
-  accumulate_point(s0, q0, fx, fy, ed, filt, huber, acc);
-  accumulate_point(s1, q1, fx, fy, ed, filt, huber, acc);
-}
-
-template <typename PTR>
-__device__ __forceinline__ void eval_one(const f4v p0, PTR dtm, int w, const float* R, const float* T, float fx, float fy,
-                                         float cx, float cy, float wlim, float hlim, float ed, bool filt, float huber,
-                                         float* acc) {
-  const PtState s0 = project_point(p0, R, T, fx, fy, cx, cy, wlim, hlim, true);
-  const DtPatch q0 = load_patch(dtm, w, s0.ix, s0.iy);
-  accumulate_point(s0, q0, fx, fy, ed, filt, huber, acc);
-}
-
-// TrackerNew::evalCostFunction's per-point term, tracker.cpp:371-389
-template <typename PTR>
-__device__ __forceinline__ float cost_point(const f4v p, PTR dtm, int w, int h, const float* R, const float* T, float fx,
-                                            float fy, float cx, float cy, float ed, bool filt) {
-  const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
-  const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
-  const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
-  const float u = __fdiv_rn(fx * X, Z) + cx;
-  const float v = __fdiv_rn(fy * Y, Z) + cy;
-  float c = 0.0f;
-  if (u >= 0 && u < (float)w && v >= 0 && v < (float)h) {
-    const float r = dtm[(int)floorf(v) * w + (int)floorf(u)];
-    if (!(r > ed && filt)) c = r;
-  }
-  return c;
-}
-
-// One residual evaluation over this thread's share of the level: the first TRACK_MAXP points
-// come from registers (loaded once per level), any overflow streams from HBM/L2.
-template <typename PTR>
-__device__ __forceinline__ void eval_level(const f4v* preg, gf4p pts, int first, int stride, int N, PTR dtm, int w,
-                                           const float* R, const float* T, float fx, float fy, float cx, float cy,
-                                           float wlim, float hlim, float ed, bool filt, float huber, float* acc) {
+// wave-uniform pose of a candidate: SGPRs
+__device__ __forceinline__ void load_pose(const Cand& c, float* R, float* T) {
 #pragma unroll
-  for (int k = 0; k < TRACK_MAXP; ++k) {
-    // (measured alternatives: two predicated points in flight 0.544 ms vs 0.505 ms for this form;
-    //  skipping the cluster exchange on small levels by evaluating them redundantly: 0.501 ms, not kept)
-    if (first + k * stride < N) eval_one(preg[k], dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
-  }
-  for (int i = first + TRACK_MAXP * stride; i < N; i += stride)
-    eval_one(pts[i], dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
+  for (int i = 0; i < 9; ++i) R[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.R[i])));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.T[i])));
 }
 
-template <typename PTR>
-__device__ __forceinline__ float cost_level(const f4v* preg, gf4p pts, int first, int stride, int N, PTR dtm, int w, int h,
-                                            const float* R, const float* T, float fx, float fy, float cx, float cy, float ed,
-                                            bool filt) {
-  float cost = 0.0f;
+// NE error-only candidates of one point, interleaved: all projections, then all 4*NE corner loads, then the
+// arithmetic -- the three L2 round trips overlap instead of queueing behind one another
+template <int NE>
+__device__ __forceinline__ void error_points(const f4v p, gf32p dtm, const float (*R)[9], const float (*T)[3], const Cam& c,
+                                             float ed, bool filt, float huber, float* e) {
+  PtState s[NE];
+  float d00[NE], d10[NE], d01[NE], d11[NE];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) s[j] = project_point(p, R[j], T[j], c, true);
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    gf32p q = dtm + s[j].iy * c.w + s[j].ix;
+    d00[j] = q[0]; d10[j] = q[1]; d01[j] = q[c.w]; d11[j] = q[c.w + 1];
+  }
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    const float dxdy = s[j].dx * s[j].dy;
+    const float w11 = dxdy, w01 = s[j].dy - dxdy, w10 = s[j].dx - dxdy, w00 = ((1.0f - s[j].dx) - s[j].dy) + dxdy;
+    float res = ((w11 * d11[j] + w01 * d01[j]) + w10 * d10[j]) + w00 * d00[j];
+    const bool good = s[j].valid && !(res > ed && filt);
+    if (!good) res = 0.0f;
+    const float wr = (res <= huber) ? 1.0f : __fdiv_rn(huber, res);
+    accumulate_error(res, wr, good, e + 3 * j);
+  }
+}
+
+template <int NE>
+__device__ __forceinline__ void error_block(const Cand* cand, const f4v* preg, gf4p pts, int first, int stride, int N, gf32p dtm,
+                                            const Cam& cam, float ed, bool filt, float huber, float* e) {
+  float R[NE][9], T[NE][3];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) load_pose(cand[1 + j], R[j], T[j]);
 #pragma unroll
   for (int k = 0; k < TRACK_MAXP; ++k)
-    if (first + k * stride < N) cost += cost_point(preg[k], dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
-  for (int i = first + TRACK_MAXP * stride; i < N; i += stride)
-    cost += cost_point(pts[i], dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
-  return cost;
+    if (first + k * stride < N) error_points<NE>(preg[k], dtm, R, T, cam, ed, filt, huber, e + 3);
+  for (int i = first + TRACK_MAXP * stride; i < N; i += stride) error_points<NE>(pts[i], dtm, R, T, cam, ed, filt, huber, e + 3);
 }
 
 // ---- the kernel ---------------------------------------------------------------
@@ -490,104 +591,120 @@ __device__ __forceinline__ float cost_level(const f4v* preg, gf4p pts, int first
 // ONE: the single pair of the sequential API arrives by value in the kernel-argument segment (no
 // H2D copy of the descriptor in front of the launch); otherwise descs[] lives in HBM (batches).
 // epoch_base: mailbox epochs keep counting across launches, so the mailbox is never re-zeroed.
+//
+// One PASS = evaluate the candidates of s_pass/s_cand (all waves) -> barrier -> the kspec "solver" waves each
+// get the totals (LDS sums of the workgroup; through the mailbox when the level is split over the cluster),
+// take the LM decision redundantly and each solve + exponentiate ONE candidate of the next pass -> barrier.
 template <bool ONE>
 __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDesc one, const PairDesc* __restrict__ descs,
                                                                    TrackParams prm, revo_pair_result* __restrict__ out,
                                                                    EvalOut* __restrict__ eval_out, u64* __restrict__ mail,
                                                                    int n_pairs, int cluster, unsigned epoch_base) {
-  __shared__ Ctrl s_ctrl;
-  __shared__ W0State s;
-  __shared__ float s_part[NWAVES][32];
+  __shared__ Cand s_cand[2][KMAX];
+  __shared__ PassCtl s_pass[2];
+  __shared__ LMState s_st[2];
+  __shared__ float s_part[NWAVES][NVAL];
+  __shared__ int s_evals[REVO_L];  // residual evaluations per level, in the reference's count (wave 0 / lane 0 only)
+#ifdef REVO_TRACK_PROFILE
+  __shared__ long long s_prof[6];
+#endif
   // XCD-affine mapping: all members of a pair share blockIdx % 8 (speed only, never correctness)
   const int b = blockIdx.x;
   const int pair = (b / (8 * cluster)) * 8 + (b % 8);
   const int member = (b / 8) % cluster;
   if (pair >= n_pairs) return;
   const PairDesc& d = ONE ? one : descs[pair];
-  u64* mail_pair = mail + (size_t)pair * 2 * cluster * 32;
+  u64* mail_pair = mail + (size_t)pair * 2 * cluster * NVAL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int stride = cluster * TRACK_THREADS;
-  const int first = member * TRACK_THREADS + tid;
+  const int kspec = prm.kspec < 1 ? 1 : (prm.kspec > KMAX ? KMAX : prm.kspec);
   unsigned epoch = epoch_base;
   int cur_level = -1;
   f4v preg[TRACK_MAXP > 0 ? TRACK_MAXP : 1];
 #pragma unroll
   for (int k = 0; k < TRACK_MAXP; ++k) preg[k] = f4v{0.f, 0.f, 1.f, 1.f};
+  int Nl[REVO_L];  // point counts of the levels: read once (they sit in HBM behind a pointer)
+#pragma unroll
+  for (int i = 0; i < REVO_L; ++i) Nl[i] = d.npts[i];
+  float abv = 0.0f;  // solver waves: lane k < 27 keeps entry k of the accepted A/n (21) and (sum w r v)/n (6)
 
-  if (wave == 0) {  // ---- initial control word
+  if (wave == 0) {  // ---- pass 0
     float R0[9], T0[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R0[i] = d.R[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) T0[i] = d.T[i];
-    int mode = MODE_EVAL, phase = PH_LEVEL_FIRST, level = prm.lvl_begin, flags = 0;
-    float Rp[9], Tp[3];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Rp[i] = R0[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) Tp[i] = T0[i];
+    PassCtl pc{MODE_EVAL, prm.lvl_begin, 1, PH_FIRST};
+    int flags = 0;
+    float q0[4];
+    quat_from_R(R0, q0);
     if (prm.eval_only) {
-      phase = PH_EVAL_ONLY;
+      pc.phase = PH_EVAL_ONLY;
     } else if (prm.check_init) {  // tracker.cpp:314 runs BEFORE Sophus::SE3f(R,T) (optimizer.cpp:241)
-      mode = MODE_COST; phase = PH_COST_EYE; level = prm.pyr_min_lvl;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Rp[i] = (i % 4 == 0) ? 1.0f : 0.0f;
-      Tp[0] = Tp[1] = Tp[2] = 0.0f;
+      pc.mode = MODE_COST; pc.level = prm.pyr_min_lvl; pc.ncand = 2;
+    } else if (!is_orthogonal(R0)) {  // Sophus::SE3f(R,T) would abort
+      flags = 2;
+      pc.mode = MODE_DONE;
     }
     if (lane == 0) {
-      float q0[4];
-      quat_from_R(R0, q0);
+      LMState& s = s_st[0];
 #pragma unroll
       for (int i = 0; i < 4; ++i) s.q[i] = q0[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) s.t[i] = T0[i];
       s.lastErr = s.last_residual = __builtin_nanf("");
-      s.lambda = 0.f; s.incsq = 0.f; s.costEye = 0.f;
-      s.iteration = 0; s.incTry = 0; s.phase = phase; s.flags = flags; s.total_evals = 0;
+      s.lambda = 0.f;
+      s.iteration = 0; s.incTry = 0; s.flags = flags; s.total_evals = 0;
       s.good = 0; s.bad = 0; s.sumw = 0.f; s.sumu = 0.f;
 #pragma unroll
-      for (int i = 0; i < REVO_L; ++i) s.evals[i] = 0;
-#ifdef REVO_TRACK_PROFILE
-      for (int i = 0; i < 6; ++i) s.prof[i] = 0;
-#endif
+      for (int i = 0; i < REVO_L; ++i) s_evals[i] = 0;
+      Cand& c0 = s_cand[0][0];
+      Cand& c1 = s_cand[0][1];
+      if (pc.mode == MODE_COST) {  // candidate 0 = identity, candidate 1 = the given initialisation (tracker.cpp:272-273)
 #pragma unroll
-      for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rp[i];
+        for (int i = 0; i < 9; ++i) { c0.R[i] = (i % 4 == 0) ? 1.0f : 0.0f; c1.R[i] = R0[i]; }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) s_ctrl.T[i] = Tp[i];
-      if (!prm.eval_only && !prm.check_init && !is_orthogonal(R0)) {  // Sophus::SE3f(R,T) would abort
-        s.flags = 2;
-        mode = MODE_DONE;
+        for (int i = 0; i < 3; ++i) { c0.T[i] = 0.0f; c1.T[i] = T0[i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c0.R[i] = R0[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c0.T[i] = T0[i];
       }
-      s_ctrl.level = level;
-      s_ctrl.mode = mode;
+      s_pass[0] = pc;
+#ifdef REVO_TRACK_PROFILE
+      for (int i = 0; i < 6; ++i) s_prof[i] = 0;
+#endif
     }
   }
   __syncthreads();
 
-  for (;;) {
-    const int mode = s_ctrl.mode;
-    if (mode == MODE_DONE) break;
-    const int l = s_ctrl.level;
-    float R[9], T[3];  // wave-uniform: keep them in SGPRs
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ctrl.R[i])));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_ctrl.T[i])));
-    const float fx = prm.cam[l].fx, fy = prm.cam[l].fy, cx = prm.cam[l].cx, cy = prm.cam[l].cy;
-    const int w = prm.cam[l].w, h = prm.cam[l].h;
+  int p = 0;
+  for (;; ++p) {
+    const int pb = p & 1, nb = pb ^ 1;
+    const PassCtl pc = s_pass[pb];
+    if (pc.mode == MODE_DONE) break;
+    const int l = pc.level;
+    Cam cam;
+    cam.fx = prm.cam[l].fx; cam.fy = prm.cam[l].fy; cam.cx = prm.cam[l].cx; cam.cy = prm.cam[l].cy;
+    cam.w = prm.cam[l].w; cam.h = prm.cam[l].h;
+    cam.wlim = (float)(cam.w - 2); cam.hlim = (float)(cam.h - 2);
     gf4p pts = (gf4p)d.pts[l];
     gf32p dtm = (gf32p)d.dt[l];
-    const int N = d.npts[l];
+    int N = Nl[0];
+#pragma unroll
+    for (int i = 1; i < REVO_L; ++i) N = (l == i) ? Nl[i] : N;
+    // few points: every member evaluates the whole level itself (same threads, same order, same bits),
+    // so the pass needs no exchange
+    const bool redundant = cluster == 1 || N <= prm.redundant_n;
+    const int stride = redundant ? TRACK_THREADS : cluster * TRACK_THREADS;
+    const int first = redundant ? tid : member * TRACK_THREADS + tid;
     ++epoch;
 #ifdef REVO_TRACK_PROFILE
     const long long tp0 = clock64();
 #endif
-
     if (l != cur_level) {
       // Level entry (block-uniform): this thread's first points go to registers for every evaluation
-      // of the level -- only the pose changes between them (optimizer.cpp:250-305).  (Staging the
-      // coarse DT planes in LDS was measured at 0 % gain -- they sit in L2 -- and cost 76.8 KB of
-      // LDS per CU that the co-running build kernels need.)
+      // of the level -- only the pose changes between them (optimizer.cpp:250-305).
       cur_level = l;
 #pragma unroll
       for (int k = 0; k < TRACK_MAXP; ++k) {
@@ -597,26 +714,54 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
     }
     const float ed = prm.edge_distance[l];
     const bool filt = prm.use_edge_filter != 0;
-    if (mode == MODE_COST) {
-      // TrackerNew::evalCostFunction, tracker.cpp:357-393: nearest-pixel DT lookup
-      float cost = cost_level(preg, pts, first, stride, N, dtm, w, h, R, T, fx, fy, cx, cy, ed, filt);
+    float e[16];
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) cost += __shfl_xor(cost, m);
-      if (lane < 32) s_part[wave][lane] = (lane == 0) ? cost : 0.0f;
+    for (int k = 0; k < 16; ++k) e[k] = 0.0f;
+    if (pc.mode == MODE_COST) {
+      // TrackerNew::evalCostFunction, tracker.cpp:357-393: nearest-pixel DT lookup, both poses in one pass
+      float R[2][9], T[2][3];
+      load_pose(s_cand[pb][0], R[0], T[0]);
+      load_pose(s_cand[pb][1], R[1], T[1]);
+      float c0 = 0.0f, c1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < TRACK_MAXP; ++k)
+        if (first + k * stride < N) {
+          c0 += cost_point(preg[k], dtm, R[0], T[0], cam, ed, filt);
+          c1 += cost_point(preg[k], dtm, R[1], T[1], cam, ed, filt);
+        }
+      for (int i = first + TRACK_MAXP * stride; i < N; i += stride) {
+        const f4v pt = pts[i];
+        c0 += cost_point(pt, dtm, R[0], T[0], cam, ed, filt);
+        c1 += cost_point(pt, dtm, R[1], T[1], cam, ed, filt);
+      }
+      c0 += lane_xor<32>(c0); c1 += lane_xor<32>(c1);
+      c0 += lane_xor<16>(c0); c1 += lane_xor<16>(c1);
+      c0 += lane_xor<8>(c0); c1 += lane_xor<8>(c1);
+      c0 += lane_xor<4>(c0); c1 += lane_xor<4>(c1);
+      c0 += lane_xor<2>(c0); c1 += lane_xor<2>(c1);
+      c0 += lane_xor<1>(c0); c1 += lane_xor<1>(c1);
+      if (lane < NVAL) s_part[wave][lane] = (lane == ESLOT) ? c0 : (lane == ESLOT + 1 ? c1 : 0.0f);
     } else {
       const float huber = prm.huber_edge;
-      const float wlim = (float)(w - 2), hlim = (float)(h - 2);
       float acc[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-      eval_level(preg, pts, first, stride, N, dtm, w, R, T, fx, fy, cx, cy, wlim, hlim, ed, filt, huber, acc);
-      butterfly_step<16, 32>(acc, lane);
-      butterfly_step<8, 16>(acc, lane);
-      butterfly_step<4, 8>(acc, lane);
-      butterfly_step<2, 4>(acc, lane);
-      butterfly_step<1, 2>(acc, lane);
-      acc[0] += __shfl_xor(acc[0], 1);
-      if ((lane & 1) == 0) s_part[wave][lane >> 1] = acc[0];
+      {  // candidate 0 in full: residual + Jacobian + normal equations
+        float R[9], T[3];
+        load_pose(s_cand[pb][0], R, T);
+#pragma unroll
+        for (int k = 0; k < TRACK_MAXP; ++k)
+          if (first + k * stride < N) full_point(preg[k], dtm, R, T, cam, ed, filt, huber, acc, e);
+        for (int i = first + TRACK_MAXP * stride; i < N; i += stride) full_point(pts[i], dtm, R, T, cam, ed, filt, huber, acc, e);
+      }
+      // the speculative retries: error only
+      if (pc.ncand == 4) error_block<3>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
+      else if (pc.ncand == 3) error_block<2>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
+      else if (pc.ncand == 2) error_block<1>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
+      reduce32(acc, lane);
+      reduce16(e, lane);
+      if (lane < 32) s_part[wave][idx32(lane)] = acc[0];
+      if (lane < 16) s_part[wave][ESLOT + idx16(lane)] = e[0];
     }
 #ifdef REVO_TRACK_PROFILE
     const long long tp1 = clock64();
@@ -624,216 +769,227 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
     __syncthreads();
 #ifdef REVO_TRACK_PROFILE
     const long long tp2 = clock64();
-    long long tp3 = tp2, tp4 = tp2, tp5 = tp2;
+    long long tp3 = tp2;
 #endif
 
-    if (wave == 0) {  // ---- wave 0: totals, cluster exchange, LM decision, next pose (all lanes uniform)
+    if (wave < kspec) {  // ---- the solver waves: totals, the LM decision (redundantly), one candidate each
       double tot = 0.0;
-      if (lane < 32) {
+      bool xok = true;
+      if (redundant || wave == 0) {
+        if (lane < NVAL) {
 #pragma unroll
-        for (int wv = 0; wv < NWAVES; ++wv) tot += (double)s_part[wv][lane];
+          for (int wv = 0; wv < NWAVES; ++wv) tot += (double)s_part[wv][lane];
+        }
       }
+      if (!redundant) {
+        if (wave == 0) cluster_publish(mail_pair, cluster, member, epoch, (float)tot, lane);
+        xok = cluster_gather(mail_pair, cluster, epoch, lane, &tot);
+      }
+      const float tf = (float)tot;  // lane v: total of value v
+#define TOT(v) rl(tf, (v))
 #ifdef REVO_TRACK_PROFILE
       tp3 = clock64();
 #endif
-      bool exchange_ok = true;
-      if (cluster > 1) exchange_ok = cluster_allgather(mail_pair, cluster, member, epoch, (float)tot, lane, &tot);
-#ifdef REVO_TRACK_PROFILE
-      tp4 = clock64();
-#endif
-      int phase = s.phase;
-      int next_mode = MODE_EVAL, next_level = l;
-      bool new_candidate = false;  // solve + exp on the accepted state
-      bool level_done = false;
-      float q[4], t[3];
+      const LMState S = s_st[pb];
+      LMState Nw = S;
+      PassCtl nx{MODE_EVAL, l, 1, PH_LM};
+      bool level_done = false, gen = false, single = false, take_ab = false;
+      float Rs[9], Ts[3];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = s.q[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) t[i] = s.t[i];
-      float lambda = s.lambda;
-      int iteration = s.iteration, incTry = s.incTry;
-      int total_evals = s.total_evals + 1;
-      int flags = s.flags;
+      for (int i = 0; i < 9; ++i) Rs[i] = 0.0f;
+      Ts[0] = Ts[1] = Ts[2] = 0.0f;
+      float n_ab = 1.0f;  // point count of the evaluation the new normal equations come from
+      int consumed = 0;   // residual evaluations of the reference's sequence decided in this pass
 
-      if (!exchange_ok) {  // a cluster member never showed up: give up loudly instead of hanging
-        flags |= 8;
-        next_mode = MODE_DONE;
-      } else if (mode == MODE_COST) {
-        const float cost = (float)__shfl(tot, 0);
-        if (phase == PH_COST_EYE) {
-          if (lane == 0) s.costEye = cost;
-          phase = PH_COST_INIT;
-          next_mode = MODE_COST;
-          if (lane == 0) {
+      if (!xok) {  // a cluster member never showed up: give up loudly instead of hanging
+        Nw.flags |= 8;
+        nx.mode = MODE_DONE;
+      } else if (pc.mode == MODE_COST) {  // tracker.cpp:272-282
+        const float costEye = TOT(ESLOT), costInit = TOT(ESLOT + 1);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = d.R[i];
+        for (int i = 0; i < 9; ++i) Rs[i] = d.R[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = d.T[i];
-          }
-        } else {  // PH_COST_INIT: tracker.cpp:277-282
-          float Rs[9], Ts[3];
+        for (int i = 0; i < 3; ++i) Ts[i] = d.T[i];
+        if (costEye < costInit) {
 #pragma unroll
-          for (int i = 0; i < 9; ++i) Rs[i] = d.R[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) Ts[i] = d.T[i];
-          if (s.costEye < cost) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Rs[i] = (i % 4 == 0) ? 1.0f : 0.0f;
-            Ts[0] = Ts[1] = Ts[2] = 0.0f;
-            flags |= 1;
-          }
-          quat_from_R(Rs, q);
-          t[0] = Ts[0]; t[1] = Ts[1]; t[2] = Ts[2];
-          phase = PH_LEVEL_FIRST;
-          next_mode = MODE_EVAL;
-          next_level = prm.lvl_begin;
-          if (!is_orthogonal(Rs)) { flags |= 2; next_mode = MODE_DONE; }  // Sophus::SE3f(R,T), optimizer.cpp:241
-          if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rs[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = Ts[i];
-          }
+          for (int i = 0; i < 9; ++i) Rs[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+          Ts[0] = Ts[1] = Ts[2] = 0.0f;
+          Nw.flags |= 1;
         }
+        quat_from_R(Rs, Nw.q);
+        Nw.t[0] = Ts[0]; Nw.t[1] = Ts[1]; Nw.t[2] = Ts[2];
+        nx.level = prm.lvl_begin; nx.phase = PH_FIRST;
+        single = true;
+        if (!is_orthogonal(Rs)) { Nw.flags |= 2; nx.mode = MODE_DONE; }  // Sophus::SE3f(R,T), optimizer.cpp:241
       } else {
-        const double n_d = __shfl(tot, 29);
-        const double sumw_d = __shfl(tot, 27);
-        const double sumu_d = __shfl(tot, 28);
-        const int good = (int)n_d;
-        const float err = __fdiv_rn((float)sumw_d, (float)good);  // optimizer.cpp:190
-        if (lane == 0) {
-          s.good = good; s.bad = N - good; s.sumw = (float)sumw_d; s.sumu = (float)sumu_d;
-          s.evals[l] += 1;
-        }
-        bool acceptA = false;
-        if (phase == PH_EVAL_ONLY) {
-          // LGS6 after finish(): A/n, b = -(sum w r v)/n, error = sum w r^2 / n
-          const double an = tot / n_d;
-          if (lane < 27) s.Aacc[lane] = an;
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          if (lane == 0 && member == 0) {
+        // error terms of candidate j: slots ESLOT + 3j .. +2 (sum w r^2, sum r^2, good count)
+        if (pc.phase == PH_EVAL_ONLY) {
+          const float n_f = TOT(ESLOT + 2);
+          const float an = __fdiv_rn(tf, n_f);  // LGS6 after finish(): A/n, b = -(sum w r v)/n, error = sum w r^2 / n
+          if (wave == 0 && member == 0) {
             EvalOut& eo = eval_out[pair];
-            int k = 0;
-            for (int r = 0; r < 6; ++r)
-              for (int c = r; c < 6; ++c) { const float v = (float)s.Aacc[k++]; eo.A[r * 6 + c] = v; eo.A[c * 6 + r] = v; }
-            for (int a = 0; a < 6; ++a) eo.b[a] = -(float)s.Aacc[21 + a];
-            eo.error = (float)(sumw_d / n_d);
-            eo.mean_err = err; eo.sum_w = (float)sumw_d; eo.sum_u = (float)sumu_d;
-            eo.good = good; eo.bad = N - good;
-          }
-          next_mode = MODE_DONE;
-        } else if (phase == PH_LEVEL_FIRST) {  // optimizer.cpp:243-250
-          acceptA = true;
-          if (lane == 0) { s.lastErr = err; s.last_residual = err; }
-          lambda = prm.lambda_initial[l];
-          iteration = 0;
-          if (iteration < prm.max_its[l]) { new_candidate = true; incTry = 0; } else level_done = true;
-          phase = PH_LM;
-        } else {  // PH_LM: accept / reject, optimizer.cpp:273-304
-          const float lastErr = s.lastErr;
-          if (err < lastErr) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = s.qn[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) t[i] = s.tn[i];
-            acceptA = true;
-            if (__fdiv_rn(err, lastErr) > prm.convergence_eps[l]) iteration = prm.max_its[l];
-            if (lane == 0) { s.lastErr = err; s.last_residual = err; }
-            lambda = (lambda <= 0.2f) ? 0.0f : lambda * prm.lambda_success_fac;
-            iteration += 1;
-            if (iteration < prm.max_its[l]) { new_candidate = true; incTry = 0; } else level_done = true;
-          } else {
-            if (!(s.incsq > prm.step_size_min[l])) {
-              level_done = true;
-            } else {
-              lambda = (lambda == 0.0f) ? 0.2f : (float)((double)lambda * powi_dd((double)prm.lambda_fail_fac, incTry));
-              new_candidate = true;  // same outer iteration, incTry keeps counting
+            if (lane < 21) {
+              int r = 0, k = lane;
+              while (k >= 6 - r) { k -= 6 - r; ++r; }
+              eo.A[r * 6 + r + k] = an;
+              eo.A[(r + k) * 6 + r] = an;
+            } else if (lane < 27) {
+              eo.b[lane - 21] = -an;
+            } else if (lane == ESLOT) {
+              eo.error = an; eo.mean_err = an; eo.sum_w = tf;
+            } else if (lane == ESLOT + 1) {
+              eo.sum_u = tf;
+            } else if (lane == ESLOT + 2) {
+              eo.good = (int)tf; eo.bad = N - (int)tf;
             }
           }
+          nx.mode = MODE_DONE;
+        } else if (pc.phase == PH_FIRST) {  // optimizer.cpp:243-250
+          const float n_f = TOT(ESLOT + 2);
+          const float err = __fdiv_rn(TOT(ESLOT), n_f);  // optimizer.cpp:190
+          Nw.good = (int)n_f; Nw.bad = N - (int)n_f; Nw.sumw = TOT(ESLOT); Nw.sumu = TOT(ESLOT + 1);
+          consumed = 1;
+          Nw.lastErr = err; Nw.last_residual = err;
+          Nw.lambda = prm.lambda_initial[l];
+          Nw.iteration = 0; Nw.incTry = 0;
+          take_ab = true; n_ab = n_f;
+          if (Nw.iteration < prm.max_its[l]) gen = true; else level_done = true;
+        } else if (pc.phase == PH_REFILL) {  // the normal equations at the pose an error-only candidate was accepted at
+          take_ab = true; n_ab = TOT(ESLOT + 2);
+          gen = true;
+        } else {  // PH_LM: consume the candidates in the reference's order, optimizer.cpp:258-304
+          for (int j = 0; j < pc.ncand; ++j) {
+            const Cand& c = s_cand[pb][j];
+            const float sw = __shfl(tf, ESLOT + 3 * j), su = __shfl(tf, ESLOT + 3 * j + 1), n_f = __shfl(tf, ESLOT + 3 * j + 2);
+            const float err = __fdiv_rn(sw, n_f);
+            Nw.good = (int)n_f; Nw.bad = N - (int)n_f; Nw.sumw = sw; Nw.sumu = su;
+            consumed += 1;
+            if (err < Nw.lastErr) {  // accepted
+#pragma unroll
+              for (int i = 0; i < 4; ++i) Nw.q[i] = c.q[i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) Nw.t[i] = c.t[i];
+              if (__fdiv_rn(err, Nw.lastErr) > prm.convergence_eps[l]) Nw.iteration = prm.max_its[l];
+              Nw.lastErr = err; Nw.last_residual = err;
+              Nw.lambda = (c.lambda <= 0.2f) ? 0.0f : c.lambda * prm.lambda_success_fac;
+              Nw.iteration += 1;
+              Nw.incTry = 0;
+              if (Nw.iteration < prm.max_its[l]) {
+                if (j == 0) { take_ab = true; n_ab = n_f; gen = true; }
+                else {  // its Jacobian was not evaluated: one full pass at that pose
+                  single = true; nx.phase = PH_REFILL;
+#pragma unroll
+                  for (int i = 0; i < 9; ++i) Rs[i] = c.R[i];
+#pragma unroll
+                  for (int i = 0; i < 3; ++i) Ts[i] = c.T[i];
+                }
+              } else {
+                level_done = true;
+              }
+              break;
+            }
+            // rejected
+            if (!(c.incsq > prm.step_size_min[l])) { level_done = true; break; }
+            Nw.lambda = lambda_after_reject(c.lambda, prm.lambda_fail_fac, c.incTry);
+            Nw.incTry = c.incTry;
+            if (S.total_evals + consumed > MAX_TOTAL_EVALS) { level_done = true; Nw.flags |= 4; break; }
+            if (j == pc.ncand - 1) gen = true;  // every candidate of the pass was rejected: the chain goes on
+          }
         }
-        if (total_evals > MAX_TOTAL_EVALS && !level_done && next_mode != MODE_DONE) { level_done = true; flags |= 4; }
-        if (acceptA) {
-          const double an = tot / n_d;  // LGS6::finish, LGSX.h:320-326
-          if (lane < 27) s.Aacc[lane] = an;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        Nw.total_evals = S.total_evals + consumed;
+        if (take_ab) abv = __fdiv_rn(tf, n_ab);  // LGS6::finish (LGSX.h:320-326): A/n and (sum w r v)/n, lane k = entry k
         if (level_done) {  // optimizer.cpp:308-309 -> next level or done (tracker.cpp:324-340)
-          float Rn[9];
-          quat_to_R(q, Rn);
-          if (l > prm.lvl_end && !(flags & 4)) {
-            next_level = l - 1;
-            phase = PH_LEVEL_FIRST;
+          quat_to_R(Nw.q, Rs);
+          Ts[0] = Nw.t[0]; Ts[1] = Nw.t[1]; Ts[2] = Nw.t[2];
+          single = true;
+          gen = false;
+          if (l > prm.lvl_end && !(Nw.flags & 4)) {
+            nx.level = l - 1; nx.phase = PH_FIRST;
             float q2[4];
-            quat_from_R(Rn, q2);  // Sophus::SE3f(R,T) of the next level
+            quat_from_R(Rs, q2);  // Sophus::SE3f(R,T) of the next level
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = q2[i];
+            for (int i = 0; i < 4; ++i) Nw.q[i] = q2[i];
           } else {
-            next_mode = MODE_DONE;
-          }
-          if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rn[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = t[i];
-          }
-        } else if (new_candidate) {  // optimizer.cpp:258-269
-          float inc[6], qn[4], tn[3], Rn[9];
-          solve6(s.Aacc, lambda, inc, lane);
-          incTry += 1;
-          const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
-          se3_exp_mul(inc, q, t, qn, tn);
-          quat_to_R(qn, Rn);
-          if (lane == 0) {
-            s.incsq = incsq;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s.qn[i] = qn[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s.tn[i] = tn[i];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) s_ctrl.R[i] = Rn[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s_ctrl.T[i] = tn[i];
+            nx.mode = MODE_DONE;
           }
         }
       }
-      if (lane == 0) {
+      if (gen && nx.mode != MODE_DONE) {  // candidate `wave` of the next pass: optimizer.cpp:258-269
+        float lam = Nw.lambda;
+        int tr = Nw.incTry;
+        for (int i = 0; i < wave; ++i) {  // as if candidates 0..wave-1 had been rejected
+          tr += 1;
+          lam = lambda_after_reject(lam, prm.lambda_fail_fac, tr);
+        }
+        tr += 1;
+        float inc[6], qn[4], tn[3], Rn[9];
+        solve6_ldlt(abv, lam, inc, lane);
+        const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
+        se3_exp_mul(inc, Nw.q, Nw.t, qn, tn);
+        quat_to_R(qn, Rn);
+        if (lane == 0) {
+          Cand& c = s_cand[nb][wave];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s.q[i] = q[i];
+          for (int i = 0; i < 9; ++i) c.R[i] = Rn[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s.t[i] = t[i];
-        s.lambda = lambda; s.iteration = iteration; s.incTry = incTry; s.phase = phase;
-        s.flags = flags; s.total_evals = total_evals;
-        s_ctrl.level = next_level;
-        s_ctrl.mode = next_mode;
+          for (int i = 0; i < 3; ++i) { c.T[i] = tn[i]; c.t[i] = tn[i]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c.q[i] = qn[i];
+          c.incsq = incsq; c.lambda = lam; c.incTry = tr;
+        }
+        nx.ncand = kspec; nx.phase = PH_LM;
       }
-#ifdef REVO_TRACK_PROFILE
-      tp5 = clock64();
-#endif
+      if (wave == 0 && lane == 0) {
+        if (single || nx.mode == MODE_DONE) {
+          Cand& c = s_cand[nb][0];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) c.R[i] = Rs[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) c.T[i] = Ts[i];
+        }
+        s_st[nb] = Nw;
+        s_pass[nb] = nx;
+        s_evals[l] += consumed;
+      }
+#undef TOT
     }
+#ifdef REVO_TRACK_PROFILE
+    const long long tp5 = clock64();
+#endif
     __syncthreads();
 #ifdef REVO_TRACK_PROFILE
     if (tid == 0) {
       const long long tp6 = clock64();
-      s.prof[0] += tp1 - tp0; s.prof[1] += tp2 - tp1; s.prof[2] += tp3 - tp2; s.prof[3] += tp4 - tp3; s.prof[4] += tp5 - tp4; s.prof[5] += tp6 - tp5;
+      s_prof[0] += tp1 - tp0; s_prof[1] += tp2 - tp1; s_prof[2] += tp3 - tp2; s_prof[3] += 0; s_prof[4] += tp5 - tp3;
+      s_prof[5] += tp6 - tp5;
     }
 #endif
   }
 
   if (tid == 0 && member == 0 && !prm.eval_only) {
+    const LMState& s = s_st[p & 1];
+    const Cand& c = s_cand[p & 1][0];
     revo_pair_result r;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.R[i] = s_ctrl.R[i];
+    for (int i = 0; i < 9; ++i) r.R[i] = c.R[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) r.T[i] = s_ctrl.T[i];
+    for (int i = 0; i < 3; ++i) r.T[i] = c.T[i];
+    if (s.flags & (2 | 8)) {  // no pose was produced: hand the input back, the flags say why
+#pragma unroll
+      for (int i = 0; i < 9; ++i) r.R[i] = d.R[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r.T[i] = d.T[i];
+    }
     r.err = s.last_residual;
     r.good = s.good;
     r.bad = s.bad;
     // tracker.cpp:351-352
     r.status = ((double)s.good / (double)s.bad < 4.0) ? REVO_TRACKER_STATE_NEW_KF : REVO_TRACKER_STATE_OK;
 #pragma unroll
-    for (int i = 0; i < REVO_L; ++i) r.evals[i] = s.evals[i];
+    for (int i = 0; i < REVO_L; ++i) r.evals[i] = s_evals[i];
 #ifdef REVO_TRACK_PROFILE
-    for (int i = 0; i < 6; ++i) r.evals[i] = (int)(s.prof[i] / 16);  // profile build: phase cycles / 16
+    for (int i = 0; i < 5; ++i) r.evals[i] = (int)(s_prof[i] / 16);  // profile build: phase cycles / 16 ...
+    r.evals[5] = p;                                                   // ... and the number of passes
 #endif
     r.flags = s.flags;
     r.n_pts0 = d.npts[0];
@@ -841,7 +997,31 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   }
 }
 
+// A.ldlt().solve(b) alone (optimizer.cpp:258-262), for the parity tests of the solver
+__global__ void __launch_bounds__(64) k_solve6(const float* __restrict__ Ab, int n, float* __restrict__ x_out) {
+  const int lane = threadIdx.x;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const float* src = Ab + (size_t)i * 43;  // A (36, symmetric), b (6), lambda (1)
+    float abv = 0.0f;
+    if (lane < 21) {
+      int r = 0, k = lane;
+      while (k >= 6 - r) { k -= 6 - r; ++r; }
+      abv = src[r * 6 + r + k];
+    } else if (lane < 27) {
+      abv = src[36 + lane - 21];
+    }
+    float x[6];
+    solve6_ldlt(abv, src[42], x, lane);
+    if (lane == 0)
+      for (int k = 0; k < 6; ++k) x_out[(size_t)i * 6 + k] = x[k];
+  }
+}
+
 }  // namespace
+
+void launch_solve6(const float* d_Ab, int n, float* d_x, hipStream_t s) {
+  hipLaunchKernelGGL(k_solve6, dim3(n < 256 ? n : 256), dim3(64), 0, s, d_Ab, n, d_x);
+}
 
 int track_blocks_per_cu() {
   int nb = 0;
@@ -866,7 +1046,7 @@ static unsigned next_epoch_base(unsigned* epoch_io, unsigned long long* d_mail, 
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval, int n_pairs,
                   unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s) {
   static_assert(MAX_TOTAL_EVALS + 64 < TRACK_EPOCH_WINDOW, "epoch window too small");
-  const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * 32, s);
+  const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * NVAL, s);
   const int groups = (n_pairs + 7) / 8;
   hipLaunchKernelGGL(k_track<false>, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, PairDesc{}, d_descs, prm, d_out,
                      d_eval, (u64*)d_mail, n_pairs, cluster, base);
@@ -875,7 +1055,7 @@ void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_res
 // one pair, descriptor by value; out / eval_out may be device-visible pinned host memory
 void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
                       unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s) {
-  const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * 2 * (size_t)cluster * 32, s);
+  const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * 2 * (size_t)cluster * NVAL, s);
   hipLaunchKernelGGL(k_track<true>, dim3(8 * cluster), dim3(TRACK_THREADS), 0, s, desc, (const PairDesc*)nullptr, prm, out,
                      eval_out, (u64*)d_mail, 1, cluster, base);
 }

@@ -253,7 +253,7 @@ def test_track_level_and_track_frames_parity(api, ro, pair640):
     for lvl in (2, 1):
         e_g, R_g, T_g = gt.mOptimizer.trackFrames(g_ref, g_cur, np.eye(3), np.zeros(3), lvl)
         R_o, T_o, e_o, info_o, ev_o, ab = ot.track_level(o_ref, o_cur, np.eye(3), np.zeros(3), lvl)
-        assert rot_angle(R_g, R_o) < 5 * ROT_TOL and np.linalg.norm(T_g - T_o) < 5 * TRANS_TOL, (lvl, T_g, T_o)
+        assert rot_angle(R_g, R_o) < ROT_TOL and np.linalg.norm(T_g - T_o) < TRANS_TOL, (lvl, T_g, T_o)
     # full coarse-to-fine (TrackerNew::trackFrames)
     st_g, R_g, T_g, err_g = gt.trackFrames(np.eye(3), np.zeros(3), g_ref, g_cur)
     r_o = ot.trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
@@ -486,12 +486,22 @@ def test_many_pairs_pose_parity_statistics(api, ro):
     print("pairs within 1e-5: %d/%d; max diff %.2e rad %.2e m; median GT error gpu %.2e oracle %.2e m"
           % (tight.sum(), n, drot.max(), dtr.max(), np.median(eg), np.median(eo)))
     assert tight.sum() >= int(0.9 * n)
+    # the stated tolerance, with an explicit allowance: at most 2 of the 48 pairs may sit inside the LM's 0.999
+    # convergence slack (a borderline accept/stop decision flips), and those by millimetres at most
+    outside = ~((drot < ROT_TOL) & (dtr < TRANS_TOL))
+    assert outside.sum() <= 2, (np.nonzero(outside)[0].tolist(), drot[outside], dtr[outside])
     assert drot.max() < 5e-3 and dtr.max() < 5e-3
     assert abs(np.median(eg) - np.median(eo)) < 1e-4
 
 
-def test_batch_matches_single_and_full_size_properties(api, ro):
+def test_batch_matches_single_and_full_size_properties(api, ro, monkeypatch):
     import torch
+    # same partition of the point lists in the batch and in the single-pair launch (8 workgroups per pair, same
+    # small-level threshold): then the two paths must agree bit for bit
+    monkeypatch.setenv("REVO_TRACK_CLUSTER_ONE", "8")
+    monkeypatch.setenv("REVO_TRACK_CLUSTER", "8")
+    monkeypatch.setenv("REVO_TRACK_REDUNDANT_ONE", "400")
+    monkeypatch.setenv("REVO_TRACK_REDUNDANT_BATCH", "400")
     s = tum_settings(4)
     s.hist_patch[3] = 0
     n_pairs = 4
