@@ -75,7 +75,7 @@ struct TrackParams {
   int lvl_begin, lvl_end;         // levels to run (lvl_begin >= lvl_end), inclusive
   int check_init;                 // tracker.cpp:268
   int eval_only;                  // 1: one calcErrorAndBuffers+calculateWarpUpdate at (R,T), lvl_begin
-  int kspec;                      // LM candidates evaluated per pass: 1 full + (kspec-1) error-only retries (1..TRACK_KMAX)
+  int kspec[REVO_L];              // per level: LM candidates evaluated per pass, 1 full + (kspec-1) error-only retries (1..TRACK_KMAX)
   int redundant_n;                // levels with at most this many points are evaluated by every cluster member (no exchange)
   float lambda_success_fac, lambda_fail_fac;
   float lambda_initial[REVO_L], step_size_min[REVO_L], convergence_eps[REVO_L];
@@ -99,7 +99,9 @@ struct EvalOut {
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
 #define NMS_ROWS 6                  // output rows per k_canny_nms thread (8 pixels wide)
 #define REVO_HYST_LDS_MAX 163000    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
+#ifndef TRACK_THREADS
 #define TRACK_THREADS 512
+#endif
 #ifndef TRACK_MAX_CLUSTER
 #define TRACK_MAX_CLUSTER 32       // workgroups per frame-pair (one XCD holds 32 CUs)
 #endif

@@ -209,7 +209,16 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
     t->edge_distance[i] = c->os.edge_distance_lvl[i];
   }
   t->huber_edge = c->os.huber_edge; t->use_edge_filter = c->os.use_edge_filter;
-  t->kspec = env_int("REVO_TRACK_KSPEC", TRACK_KMAX, 1, TRACK_KMAX);
+  // speculation depth per level: REVO_TRACK_KSPEC = one digit for all levels or one digit per level (finest first)
+  {
+    const char* e = getenv("REVO_TRACK_KSPEC");
+    const size_t n = e ? strlen(e) : 0;
+    for (int i = 0; i < REVO_L; ++i) {
+      int k = TRACK_KMAX;
+      if (n == 1) k = e[0] - '0'; else if (n > 1) k = e[std::min<size_t>(i, n - 1)] - '0';
+      t->kspec[i] = std::max(1, std::min(TRACK_KMAX, k));
+    }
+  }
   t->redundant_n = env_int("REVO_TRACK_REDUNDANT_BATCH", 400, 0, 1 << 30);
   for (int l = 0; l < c->geom.n_levels; ++l) {
     const LevelGeom& v = c->geom.lv[l];
@@ -697,6 +706,13 @@ extern "C" int revo_optimizer_solve6(revo_ctx* c, int n, const float* A36_b6_lam
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   hipFree(d_in); hipFree(d_out);
   if (e != hipSuccess) return fail(REVO_ERR_HIP, std::string("revo_optimizer_solve6: ") + hipGetErrorString(e));
+  return REVO_OK;
+}
+
+// profile builds (-DREVO_TRACK_PROFILE): the phase cycle counters the last single-pair launch left in the EvalOut record
+extern "C" int revo_debug_track_profile_(revo_ctx* c, float out13[13]) {
+  if (!c || !out13) return REVO_ERR_INVALID_ARG;
+  memcpy(out13, c->h_eval->A, sizeof(float) * 13);
   return REVO_OK;
 }
 

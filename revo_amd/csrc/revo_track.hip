@@ -124,45 +124,33 @@ __device__ __forceinline__ bool is_orthogonal(const float* R) {  // rotation_mat
   return sqrtf(n2) < 1e-5f && det > 0.0f;
 }
 
-// sin / cos for the LM increments (|x| is ~1e-2 .. 1e-1): below 0.5 rad the truncated series are
-// accurate to float rounding (next terms x^11/11! < 2e-11, x^10/10! < 3e-10 relative) and avoid the
-// full-range argument reduction of sinf/cosf on the serial path (and its ~150 instructions per call site in
-// the instruction cache); an increment beyond 0.5 rad only occurs when the LM diverges.
-__device__ __forceinline__ float sin_lm(float x) {
-  if (fabsf(x) > 0.5f) return __sinf(x);  // a diverging step: the hardware sine (|err| ~1e-6) keeps the code small
-  const float x2 = x * x;
-  return x * (1.0f + x2 * (-1.0f / 6.0f + x2 * (1.0f / 120.0f + x2 * (-1.0f / 5040.0f + x2 * (1.0f / 362880.0f)))));
-}
-__device__ __forceinline__ float cos_lm(float x) {
-  if (fabsf(x) > 0.5f) return __cosf(x);
-  const float x2 = x * x;
-  return 1.0f + x2 * (-0.5f + x2 * (1.0f / 24.0f + x2 * (-1.0f / 720.0f + x2 * (1.0f / 40320.0f))));
-}
-
-// Sophus::SE3f::exp(inc) * (q,t)  (se3.hpp:723-745, so3.hpp:531-565, se3.hpp:317-321, so3.hpp:335-352)
+// Sophus::SE3f::exp(inc) * (q,t)  (se3.hpp:723-745, so3.hpp:531-565, se3.hpp:317-321, so3.hpp:335-352).
+// The coefficients sin(theta/2)/theta, cos(theta/2), (1-cos theta)/theta^2, (theta-sin theta)/theta^3 are evaluated as
+// series in theta^2 below 0.5 rad: exact to float rounding there, and without the square root, the three
+// divisions and the catastrophic cancellation of the closed forms ((1-cos theta)/theta^2 in float loses three
+// digits at theta = 0.01) -- on the serial path of every LM pass this is ~0.5 us.  Sophus' own small-angle
+// branch (theta < 1e-5: Taylor quaternion, V = R) is kept as it is.
 __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, const float* t, float* qo, float* to) {
   const float ox = a[3], oy = a[4], oz = a[5];
-  const float theta_sq = ox * ox + oy * oy + oz * oz;
-  const float theta = sqrtf(theta_sq);
-  float imag, real;
+  const float t2 = ox * ox + oy * oy + oz * oz;
+  float imag, real, ca, cb;
+  if (t2 < 0.25f) {
+    imag = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 185794560.0f, -1.0f / 645120.0f), 1.0f / 3840.0f), -1.0f / 48.0f), 0.5f);
+    real = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, -1.0f / 3715891200.0f, 1.0f / 10321920.0f), -1.0f / 46080.0f), 1.0f / 384.0f), -0.125f), 1.0f);
+    ca = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 3628800.0f, -1.0f / 40320.0f), 1.0f / 720.0f), -1.0f / 24.0f), 0.5f);
+    cb = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 39916800.0f, -1.0f / 362880.0f), 1.0f / 5040.0f), -1.0f / 120.0f), 1.0f / 6.0f);
+  } else {  // a diverging step
+    const float theta = sqrtf(t2), h = 0.5f * theta;
+    imag = __fdiv_rn(sinf(h), theta);
+    real = cosf(h);
+    ca = __fdiv_rn(1.0f - cosf(theta), t2);
+    cb = __fdiv_rn(theta - sinf(theta), t2 * theta);
+  }
+  const bool tiny = t2 < 1e-10f;  // theta < Constants<float>::epsilon() = 1e-5 (common.hpp:150-158)
   float V[9];  // row-major 3x3
   const float O[9] = {0.f, -oz, oy, oz, 0.f, -ox, -oy, ox, 0.f};
-  float O2[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
-  if (theta < 1e-5f) {
-    const float p4 = theta_sq * theta_sq;
-    imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * p4;
-    real = 1.0f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * p4;
-  } else {
-    const float h = 0.5f * theta;
-    imag = __fdiv_rn(sin_lm(h), theta);
-    real = cos_lm(h);
-  }
   const float qe[4] = {real, imag * ox, imag * oy, imag * oz};
-  if (theta < 1e-5f) {
+  if (tiny) {
     float Rm[9];
     quat_to_R(qe, Rm);
 #pragma unroll
@@ -170,8 +158,11 @@ __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, cons
 #pragma unroll
       for (int c = 0; c < 3; ++c) V[r * 3 + c] = Rm[c * 3 + r];
   } else {
-    const float ca = __fdiv_rn(1.0f - cos_lm(theta), theta_sq);
-    const float cb = __fdiv_rn(theta - sin_lm(theta), theta_sq * theta);
+    float O2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
 #pragma unroll
     for (int i = 0; i < 9; ++i) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * O[i]) + cb * O2[i];
   }
@@ -606,7 +597,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   __shared__ float s_part[NWAVES][NVAL];
   __shared__ int s_evals[REVO_L];  // residual evaluations per level, in the reference's count (wave 0 / lane 0 only)
 #ifdef REVO_TRACK_PROFILE
-  __shared__ long long s_prof[6];
+  __shared__ long long s_prof[12];
+#define PROF_MARK(var) const long long var = clock64()
+#else
+#define PROF_MARK(var)
 #endif
   // XCD-affine mapping: all members of a pair share blockIdx % 8 (speed only, never correctness)
   const int b = blockIdx.x;
@@ -616,7 +610,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   const PairDesc& d = ONE ? one : descs[pair];
   u64* mail_pair = mail + (size_t)pair * 2 * cluster * NVAL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kspec = prm.kspec < 1 ? 1 : (prm.kspec > KMAX ? KMAX : prm.kspec);
+  int kmax = 1;  // solver waves: the deepest speculation of any level
+#pragma unroll
+  for (int i = 0; i < REVO_L; ++i) kmax = prm.kspec[i] > kmax ? prm.kspec[i] : kmax;
+  kmax = kmax > KMAX ? KMAX : kmax;
   unsigned epoch = epoch_base;
   int cur_level = -1;
   f4v preg[TRACK_MAXP > 0 ? TRACK_MAXP : 1];
@@ -672,7 +669,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       }
       s_pass[0] = pc;
 #ifdef REVO_TRACK_PROFILE
-      for (int i = 0; i < 6; ++i) s_prof[i] = 0;
+      for (int i = 0; i < 12; ++i) s_prof[i] = 0;
 #endif
     }
   }
@@ -754,14 +751,19 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
           if (first + k * stride < N) full_point(preg[k], dtm, R, T, cam, ed, filt, huber, acc, e);
         for (int i = first + TRACK_MAXP * stride; i < N; i += stride) full_point(pts[i], dtm, R, T, cam, ed, filt, huber, acc, e);
       }
+      PROF_MARK(te1);
       // the speculative retries: error only
       if (pc.ncand == 4) error_block<3>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
       else if (pc.ncand == 3) error_block<2>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
       else if (pc.ncand == 2) error_block<1>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
+      PROF_MARK(te2);
       reduce32(acc, lane);
       reduce16(e, lane);
       if (lane < 32) s_part[wave][idx32(lane)] = acc[0];
       if (lane < 16) s_part[wave][ESLOT + idx16(lane)] = e[0];
+#ifdef REVO_TRACK_PROFILE
+      if (tid == 0) { s_prof[6] += te1 - tp0; s_prof[7] += te2 - te1; }
+#endif
     }
 #ifdef REVO_TRACK_PROFILE
     const long long tp1 = clock64();
@@ -772,7 +774,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
     long long tp3 = tp2;
 #endif
 
-    if (wave < kspec) {  // ---- the solver waves: totals, the LM decision (redundantly), one candidate each
+    if (wave < kmax) {  // ---- the solver waves: totals, the LM decision (redundantly), one candidate each
       double tot = 0.0;
       bool xok = true;
       if (redundant || wave == 0) {
@@ -914,7 +916,9 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
           }
         }
       }
-      if (gen && nx.mode != MODE_DONE) {  // candidate `wave` of the next pass: optimizer.cpp:258-269
+      const int kspec = prm.kspec[l] < 1 ? 1 : (prm.kspec[l] > KMAX ? KMAX : prm.kspec[l]);  // gen stays on level l
+      PROF_MARK(td1);
+      if (gen && nx.mode != MODE_DONE && wave < kspec) {  // candidate `wave` of the next pass: optimizer.cpp:258-269
         float lam = Nw.lambda;
         int tr = Nw.incTry;
         for (int i = 0; i < wave; ++i) {  // as if candidates 0..wave-1 had been rejected
@@ -924,6 +928,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
         tr += 1;
         float inc[6], qn[4], tn[3], Rn[9];
         solve6_ldlt(abv, lam, inc, lane);
+        PROF_MARK(td2);
+#ifdef REVO_TRACK_PROFILE
+        if (tid == 0) { s_prof[8] += td1 - tp3; s_prof[9] += td2 - td1; s_prof[10] += 1; }
+#endif
         const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
         se3_exp_mul(inc, Nw.q, Nw.t, qn, tn);
         quat_to_R(qn, Rn);
@@ -937,8 +945,8 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
           for (int i = 0; i < 4; ++i) c.q[i] = qn[i];
           c.incsq = incsq; c.lambda = lam; c.incTry = tr;
         }
-        nx.ncand = kspec; nx.phase = PH_LM;
       }
+      if (gen && nx.mode != MODE_DONE) { nx.ncand = kspec; nx.phase = PH_LM; }
       if (wave == 0 && lane == 0) {
         if (single || nx.mode == MODE_DONE) {
           Cand& c = s_cand[nb][0];
@@ -990,6 +998,11 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
 #ifdef REVO_TRACK_PROFILE
     for (int i = 0; i < 5; ++i) r.evals[i] = (int)(s_prof[i] / 16);  // profile build: phase cycles / 16 ...
     r.evals[5] = p;                                                   // ... and the number of passes
+    if (eval_out) {  // the finer split travels in the (otherwise unused) EvalOut record
+      EvalOut& eo = eval_out[pair];
+      for (int i = 0; i < 12; ++i) eo.A[i] = (float)s_prof[i];
+      eo.A[12] = (float)p;
+    }
 #endif
     r.flags = s.flags;
     r.n_pts0 = d.npts[0];

@@ -467,7 +467,8 @@ def test_many_pairs_pose_parity_statistics(api, ro):
     dep = np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])
     bt = api.BatchTracker(cam, n)
     d_res = torch.zeros(n * 96, dtype=torch.uint8, device="cuda")
-    bt.track(torch.from_numpy(bgr).cuda().data_ptr(), torch.from_numpy(dep).cuda().data_ptr(), d_res.data_ptr())
+    d_bgr, d_dep = torch.from_numpy(bgr).cuda(), torch.from_numpy(dep).cuda()  # must outlive the asynchronous launch
+    bt.track(d_bgr.data_ptr(), d_dep.data_ptr(), d_res.data_ptr())
     bt.sync()
     res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), n)
     ot = ro.Tracker(s, OptimizerSettings(), TrackerSettings())
