@@ -98,7 +98,7 @@ struct EvalOut {
 
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
 #define NMS_ROWS 6                  // output rows per k_canny_nms thread (8 pixels wide)
-#define REVO_HYST_LDS_MAX 163000    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
+#define REVO_HYST_LDS_MAX 158720    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
 #ifndef TRACK_THREADS
 #define TRACK_THREADS 512
 #endif

@@ -177,7 +177,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     v.wpr = (v.w + 31) / 32;
     v.nms_block_base = tile; tile += (4 * v.wpr * ((v.h + NMS_ROWS - 1) / NMS_ROWS) + 255) / 256;
     // the level's edge bitmap must fit the LDS of one workgroup (k_hyst)
-    if ((size_t)(v.h + 2) * (v.wpr + 2) * 4 > REVO_HYST_LDS_MAX) { *why = "image too large: (height + 2) x (ceil(width/32) + 2) bitmap words must fit 160 KB of LDS"; return -1; }
+    if (((size_t)(v.h + 2) * v.wpr + 2) * 4 > REVO_HYST_LDS_MAX) { *why = "image too large: (height + 2) x ceil(width/32) bitmap words must fit 155 KB of LDS"; return -1; }
     v.pix_base = pix; pix += v.npix;
     v.row_base = row; row += v.h;
     v.strip_base = col; col += (v.w + 63) / 64;

@@ -183,11 +183,10 @@ __device__ __forceinline__ HRow hrow(uint32_t prev, uint32_t m0, uint32_t m1, ui
   return r;
 }
 
-struct MRow { int m[10]; uint32_t dxy[8]; };  // |grad|^2 of columns -1..8; (dx | dy << 16) of columns 0..7
-
-// Sobel of the row between a (above) and c (below), b the row itself; cm[]: column masks (0 outside the image)
-__device__ __forceinline__ MRow mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm) {
-  MRow r;
+// Sobel of the row between a (above) and c (below), b the row itself: |grad|^2 of columns -1..8 into m[10],
+// (dx | dy << 16) of columns 0..7 into dxy[8]; cm[]: column masks (0 outside the image)
+__device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm, bool valid, int* m,
+                                        uint32_t* dxy) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const s2v dx = (a.d[k] + c.d[k]) + (b.d[k] + b.d[k]);
@@ -195,37 +194,32 @@ __device__ __forceinline__ MRow mag_row(const HRow& a, const HRow& b, const HRow
     // column 2k-1: low halves, column 2k: high halves
     const uint32_t lo = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x05040100u);
     const uint32_t hi = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x07060302u);
-    r.m[2 * k] = __builtin_amdgcn_sdot2(as_s2(lo), as_s2(lo), 0, false);
-    r.m[2 * k + 1] = __builtin_amdgcn_sdot2(as_s2(hi), as_s2(hi), 0, false);
-    if (k > 0) r.dxy[2 * k - 1] = lo;
-    if (k < 4) r.dxy[2 * k] = hi;
+    m[2 * k] = __builtin_amdgcn_sdot2(as_s2(lo), as_s2(lo), 0, false);
+    m[2 * k + 1] = __builtin_amdgcn_sdot2(as_s2(hi), as_s2(hi), 0, false);
+    if (k > 0) dxy[2 * k - 1] = lo;
+    if (k < 4) dxy[2 * k] = hi;
   }
   // |grad|^2 outside the image is 0 (cv::Canny pads its magnitude buffer with zeros); columns 0..3 of an
-  // active thread are always inside
-  r.m[0] &= (int)cm[0];
+  // active thread are always inside; `valid` is the row's mask (a row above / below the image, an idle thread)
+  const uint32_t rv = valid ? ~0u : 0u;
+  m[0] &= (int)(cm[0] & rv);
 #pragma unroll
-  for (int k = 5; k < 10; ++k) r.m[k] &= (int)cm[k - 4];
-  return r;
-}
-__device__ __forceinline__ MRow zero_row() {
-  MRow r;
+  for (int k = 1; k < 5; ++k) m[k] &= (int)rv;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) r.m[k] = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) r.dxy[k] = 0u;
-  return r;
+  for (int k = 5; k < 10; ++k) m[k] &= (int)(cm[k - 4] & rv);
 }
 
-// NMS of one row (cv::Canny): 8 candidate bits and 8 strong bits
-__device__ __forceinline__ void nms_row(const MRow& A, const MRow& B, const MRow& C, int low, int high, uint32_t* cand,
-                                        uint32_t* strong) {
+// NMS of one row (cv::Canny): 8 candidate bits and 8 strong bits.  A, B, C: |grad|^2 of the rows above, at and
+// below; dxy: the row's own gradients
+__device__ __forceinline__ void nms_row(const int* A, const int* B, const int* C, const uint32_t* dxyB, int low, int high,
+                                        uint32_t* cand, uint32_t* strong) {
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
   uint32_t cb = 0, sb = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int i = k + 1;
-    const int m = B.m[i];
-    const uint32_t dxy = B.dxy[k];
+    const int m = B[i];
+    const uint32_t dxy = dxyB[k];
     const s2v v = as_s2(dxy);
     const s2v z = {0, 0};
     const uint32_t ab = as_u32(__builtin_elementwise_max(v, z - v));  // |dx| | |dy| << 16
@@ -235,10 +229,10 @@ __device__ __forceinline__ void nms_row(const MRow& A, const MRow& B, const MRow
     const bool horiz = ay15 < t22;
     const bool vert = ay15 > t22 + (ax << 16);
     const bool neg = (int)(dxy ^ (dxy << 16)) < 0;                    // sign(dx) != sign(dy)
-    const int diag_a = neg ? A.m[i + 1] : A.m[i - 1];
-    const int diag_b = neg ? C.m[i - 1] : C.m[i + 1];
-    const int a = horiz ? B.m[i - 1] : (vert ? A.m[i] : diag_a);
-    const int b = horiz ? B.m[i + 1] : (vert ? C.m[i] : diag_b);
+    const int diag_a = neg ? A[i + 1] : A[i - 1];
+    const int diag_b = neg ? C[i - 1] : C[i + 1];
+    const int a = horiz ? B[i - 1] : (vert ? A[i] : diag_a);
+    const int b = horiz ? B[i + 1] : (vert ? C[i] : diag_b);
     const bool ge = horiz || vert;                                    // m > a && m >= b on the axes, m > both on the diagonals
     const bool is_max = (m > a) && (ge ? (m >= b) : (m > b));
     const bool c = (m > low) && is_max;
@@ -283,25 +277,24 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     if (!has_next) next = (m1 >> 24) * 0x01010101u;
     return hrow(prev, m0, m1, next);
   };
-  auto mag_at = [&](int r, const HRow& a, const HRow& b, const HRow& c) -> MRow {
-    if (r < 0 || r >= h || !active) return zero_row();
-    return mag_row(a, b, c, cm);
-  };
-  HRow h0 = load_hrow(y0 - 2), h1 = load_hrow(y0 - 1), h2 = load_hrow(y0);
-  MRow A = mag_at(y0 - 1, h0, h1, h2);
-  h0 = load_hrow(y0 + 1);
-  MRow B = mag_at(y0, h1, h2, h0);
+  // Three gray rows (H) and three magnitude rows (M) in flight; the loop is fully unrolled and the slots are
+  // addressed with compile-time indices, so nothing moves and nothing is indexed dynamically.
+  HRow H[3];
+  int M[3][10];
+  uint32_t D[3][8];
+  H[0] = load_hrow(y0 - 2); H[1] = load_hrow(y0 - 1); H[2] = load_hrow(y0);
+  mag_row(H[0], H[1], H[2], cm, active && y0 - 1 >= 0, M[0], D[0]);                  // magnitude row y0 - 1
+  H[0] = load_hrow(y0 + 1);
+  mag_row(H[1], H[2], H[0], cm, active, M[1], D[1]);                                 // magnitude row y0
   uint2* out = pl.cs[l] + ((size_t)f * h + y0) * lv.wpr + (xg >> 2);
   const int sh = 8 * (threadIdx.x & 3);
 #pragma unroll
   for (int i = 0; i < NMS_R; ++i) {
-    // rows of gray in flight: (h1, h2, h0) -> next (h2, h0, h1) -> ...: the unrolled loop renames, nothing moves
-    HRow hn = load_hrow(y0 + i + 2);
-    const HRow& ha = (i % 3 == 0) ? h2 : (i % 3 == 1 ? h0 : h1);
-    const HRow& hb = (i % 3 == 0) ? h0 : (i % 3 == 1 ? h1 : h2);
-    MRow Cm = mag_at(y0 + i + 1, ha, hb, hn);
+    // gray rows y0+i, y0+i+1 are in H[(i+2)%3], H[i%3]; row y0+i+2 replaces the oldest, H[(i+1)%3]
+    H[(i + 1) % 3] = load_hrow(y0 + i + 2);
+    mag_row(H[(i + 2) % 3], H[i % 3], H[(i + 1) % 3], cm, active && y0 + i + 1 < h, M[(i + 2) % 3], D[(i + 2) % 3]);  // row y0+i+1
     uint32_t cb, sb;
-    nms_row(A, B, Cm, g.canny_low, g.canny_high, &cb, &sb);
+    nms_row(M[i % 3], M[(i + 1) % 3], M[(i + 2) % 3], D[(i + 1) % 3], g.canny_low, g.canny_high, &cb, &sb);
     // a quad's four bytes -> one word (DPP quad_perm: no LDS)
     uint32_t cw = cb << sh, sw = sb << sh;
     cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
@@ -309,9 +302,6 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
     sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0x4E, 0xf, 0xf, true);
     if ((threadIdx.x & 3) == 0 && y0 + i < h) out[(size_t)i * lv.wpr] = make_uint2(cw, sw);
-    if (i % 3 == 0) h1 = hn; else if (i % 3 == 1) h2 = hn; else h0 = hn;
-    A = B;
-    B = Cm;
   }
 }
 
@@ -345,112 +335,304 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
   return up | dn | S;
 }
 
+#ifdef REVO_HYST_PROFILE
+#define HP(i) if (threadIdx.x == 0) hp[i] = clock64()
+#else
+#define HP(i)
+#endif
 template <bool C_IN_LDS>
 __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl) {
   extern __shared__ uint32_t s_mem[];
-  __shared__ int s_changed[3];
+#ifdef REVO_HYST_PROFILE
+  long long hp[12];
+  for (int i = 0; i < 12; ++i) hp[i] = 0;
+#endif
+  HP(0);
   const int f = g.frame0 + blockIdx.z;
   const int l = blockIdx.x;
   const LevelGeom& lv = g.lv[l];
   const int w = lv.w, h = lv.h, wpr = lv.wpr;
-  const int pitch = wpr + 2;                     // one zero word left and right, one zero row above and below
-  uint32_t* E = s_mem;                           // (h + 2) x pitch
-  uint32_t* Cl = s_mem + (size_t)(h + 2) * pitch;  // h x wpr (C_IN_LDS)
+  const int pitch = wpr;                         // one zero row above and below (+ one pad word in front / behind)
+  uint32_t* E = s_mem + 1;                       // E[(r + 1) * pitch + c] = E(r, c), r = -1 .. h
+  const int e_words = (h + 2) * pitch + 2;
+  uint32_t* Cl = s_mem + e_words;                // h x wpr (C_IN_LDS)
   const uint2* cs = pl.cs[l] + (size_t)f * h * wpr;
   const int tid = threadIdx.x;
-  for (int i = tid; i < (h + 2) * pitch; i += HYST_THREADS) E[i] = 0u;
-  if (tid < 3) s_changed[tid] = 0;
-  __syncthreads();
+  // the zero rows above / below the level and the two pad words; everything between is written by the load
+  for (int i = tid; i < pitch + 1; i += HYST_THREADS) { s_mem[i] = 0u; s_mem[e_words - 1 - i] = 0u; }
   for (int i = tid; i < h * wpr; i += HYST_THREADS) {
     const uint2 v = cs[i];
-    const int r = i / wpr, c = i - r * wpr;
-    E[(r + 1) * pitch + c + 1] = v.y;
-    if (C_IN_LDS) Cl[i] = v.x;
+    E[pitch + i] = v.y;
+    if (C_IN_LDS) Cl[i] = v.x & ~v.y;  // the WEAK candidates (C = Cl | S, and E holds S or more at all times)
   }
   __syncthreads();
-  // strips of rpt rows: at most HYST_THREADS items, one per thread
+  HP(1);
+  // ---- union-find over the runs of weak pixels (the fast path) ---------------------------------------
+  // Strong pixels are edges already; a weak candidate (C & ~S) becomes one iff its 8-connected component of
+  // WEAK pixels touches a strong pixel.  Nodes are the horizontal runs of weak pixels inside a 32-pixel word
+  // (a few thousand per level): consecutive ids from a prefix sum over the words' run counts, a lock-free
+  // union-find over them in LDS (links to the previous word's run and to the runs of the row above, Komura-style
+  // atomicMin), roots of components touching a strong pixel get a flag, and every run reads its root's flag:
+  // a handful of barriers whatever the length of the chains (flood filling the same bitmaps needed ~27 rounds
+  // of ~6 us on the bench scenes).  Words are dealt to the threads round-robin, so a long weak line is shared
+  // by neighbouring lanes instead of queueing in one.  If the level has more runs than LDS can label, or its
+  // candidate bitmap is not in LDS (big levels), the flood fill below does the job.
+  bool done = false;
+  if (C_IN_LDS) {
+    const int nwords = h * wpr;
+    unsigned short* Bs = reinterpret_cast<unsigned short*>(Cl + nwords);                // runs before word i
+    uint32_t* parent = Cl + nwords + (nwords + 1) / 2;
+    const int cap = (int)(REVO_HYST_LDS_MAX / 4) - (e_words + nwords + (nwords + 1) / 2);  // ids that fit
+    __shared__ int s_wsum[HYST_THREADS / 64];
+    __shared__ int s_total;
+    auto weak = [&](int wi) -> uint32_t { return Cl[wi]; };
+    auto starts = [](uint32_t wk) -> uint32_t { return wk & ~(wk << 1); };               // first pixel of every run
+    // ids: exclusive prefix of the run counts (contiguous chunks -> wave scan -> 16 wave totals)
+    {
+      const int wpt = (nwords + HYST_THREADS - 1) / HYST_THREADS;
+      const int w0 = min(nwords, tid * wpt), w1 = min(nwords, w0 + wpt);
+      int mine = 0;
+      for (int wi = w0; wi < w1; ++wi) mine += __popc(starts(weak(wi)));
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+      }
+      if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+      __syncthreads();
+      int before = incl - mine;
+      for (int k = 0; k < (tid >> 6); ++k) before += s_wsum[k];
+      if (tid == HYST_THREADS - 1) s_total = before + mine;
+      for (int wi = w0; wi < w1; ++wi) {
+        Bs[wi] = (unsigned short)before;
+        before += __popc(starts(weak(wi)));
+      }
+      __syncthreads();
+    }
+    const int nruns = s_total;
+    HP(2);
+    if (nruns <= cap / 2 && nruns < 65536) {
+      done = true;
+      const uint32_t FLAG = 0x80000000u, IDM = 0x7fffffffu;
+      uint32_t* rec = parent + nruns;  // run -> (word << 5 | first bit): the phases below deal RUNS to the threads
+      // id of the run that holds pixel `bit` of word wi
+      auto id_of = [&](int wi, int bit) -> int { return (int)Bs[wi] + __popc(starts(weak(wi)) & ((2u << bit) - 1u)) - 1; };
+      auto find = [&](int x) -> int {
+        int p = (int)(parent[x] & IDM);
+        while (p != x) {
+          const int gp = (int)(parent[p] & IDM);
+          if (gp != p) atomicMin(&parent[x], (uint32_t)gp);  // path halving (parents only ever decrease)
+          x = p; p = gp;
+        }
+        return x;
+      };
+      auto unite = [&](int a2, int b2) {
+        for (;;) {
+          a2 = find(a2); b2 = find(b2);
+          if (a2 == b2) return;
+          if (a2 > b2) { const int t2 = a2; a2 = b2; b2 = t2; }
+          const uint32_t old = atomicMin(&parent[b2], (uint32_t)a2);
+          if ((int)old == b2) return;
+          b2 = (int)old;  // b2 was re-parented meanwhile: keep that link by uniting with it too
+        }
+      };
+      for (int wi = tid; wi < nwords; wi += HYST_THREADS) {
+        int me = Bs[wi];
+        for (uint32_t m = starts(weak(wi)); m; m &= m - 1, ++me) {
+          parent[me] = (uint32_t)me;
+          rec[me] = ((uint32_t)wi << 5) | (uint32_t)(__ffs(m) - 1);
+        }
+      }
+      __syncthreads();
+      const float inv_wpr = 1.0f / (float)wpr;
+      auto run_at = [&](int i, int* wi_out, uint32_t* run_out) {
+        const uint32_t rc = rec[i];
+        const int wi = (int)(rc >> 5), bit = (int)(rc & 31u);
+        const uint32_t t2 = ~(weak(wi) >> bit);                    // first zero above the run's first pixel
+        const int len = t2 ? __ffs(t2) - 1 : 32 - bit;
+        *wi_out = wi;
+        *run_out = (len >= 32 ? ~0u : ((1u << len) - 1u)) << bit;
+      };
+      // links: the run continuing from the previous word; the runs of the row above that touch this one
+      for (int me = tid; me < nruns; me += HYST_THREADS) {
+        int wi; uint32_t run;
+        run_at(me, &wi, &run);
+        int r = (int)(((float)wi + 0.5f) * inv_wpr);
+        r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
+        const int c = wi - r * wpr;
+        if ((run & 1u) && c > 0 && (weak(wi - 1) >> 31)) unite(me, id_of(wi - 1, 31));
+        if (r == 0) continue;
+        for (uint32_t a2 = weak(wi - wpr) & (run | (run << 1) | (run >> 1)); a2;) {  // one union per run above
+          const int ab = __ffs(a2) - 1;
+          a2 &= ~(a2 & ~(a2 + (1u << ab)));
+          unite(me, id_of(wi - wpr, ab));
+        }
+        if ((run & 1u) && c > 0 && (weak(wi - wpr - 1) >> 31)) unite(me, id_of(wi - wpr - 1, 31));
+        if ((run >> 31) && c < wpr - 1 && (weak(wi - wpr + 1) & 1u)) unite(me, id_of(wi - wpr + 1, 0));
+      }
+      __syncthreads();
+      // every run straight under its root (concurrent path halving flattens a list in ~log steps)
+      for (int me = tid; me < nruns; me += HYST_THREADS) parent[me] = (uint32_t)find(me);
+      __syncthreads();
+      HP(3);
+      // components that touch a strong pixel: flag the root
+      for (int me = tid; me < nruns; me += HYST_THREADS) {
+        int wi; uint32_t run;
+        run_at(me, &wi, &run);
+        int r = (int)(((float)wi + 0.5f) * inv_wpr);
+        r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
+        const int c = wi - r * wpr;
+        const uint32_t lm = c > 0 ? ~0u : 0u, rm = c < wpr - 1 ? ~0u : 0u;
+        const uint32_t* Ec = E + pitch + wi;  // strong pixels (E is still the seed bitmap)
+        const uint32_t sd = dil3(Ec[-pitch], Ec[-pitch - 1] & lm, Ec[-pitch + 1] & rm) | dil3(Ec[pitch], Ec[pitch - 1] & lm, Ec[pitch + 1] & rm) |
+                            __builtin_amdgcn_alignbit(Ec[0], Ec[-1] & lm, 31) | __builtin_amdgcn_alignbit(Ec[1] & rm, Ec[0], 1);
+        if (run & sd) atomicOr(&parent[find(me)], FLAG);
+      }
+      __syncthreads();
+      HP(4);
+      // a weak run is an edge iff its root is flagged.  E is read as the seed bitmap by nobody any more.
+      for (int me = tid; me < nruns; me += HYST_THREADS) {
+        if (!(parent[find(me)] & FLAG)) continue;
+        int wi; uint32_t run;
+        run_at(me, &wi, &run);
+        atomicOr(&E[pitch + wi], run);
+      }
+    }
+    __syncthreads();
+  }
+  if (!done) {
+  // Items = strips of rpt rows x one word column; at most HYST_THREADS of them.  After the first sweep over
+  // everything an item is revisited only when it or one of its 8 neighbours changed in the previous round,
+  // and the active items are packed into the first threads, so that late rounds (a weak chain creeping
+  // across a few strips) cost a barrier, not a sweep over the level.
+    __shared__ unsigned short s_list[HYST_THREADS];
+    __shared__ unsigned char s_act[2][HYST_THREADS];
+    __shared__ int s_n;
   const int max_strips = HYST_THREADS / wpr;  // wpr <= 64 (width <= 2048)
   const int rpt = (h + max_strips - 1) / max_strips;
   const int nstrips = (h + rpt - 1) / rpt;
-  const bool has_item = tid < nstrips * wpr;
-  const int c = tid % wpr, strip = tid / wpr;
-  const int r0 = strip * rpt, r1 = min(h, r0 + rpt) - 1;
-  for (int it = 0; it < 8192; ++it) {  // the bound only guards against a hang; the fixpoint ends the loop
+  const int n_items = nstrips * wpr;
+  s_act[0][tid] = 0; s_act[1][tid] = 0;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  int n_list = n_items;
+#ifndef REVO_HYST_MAXIT
+#define REVO_HYST_MAXIT 8192  // only guards against a hang; the fixpoint ends the loop
+#endif
+  for (int it = 0; it < REVO_HYST_MAXIT; ++it) {
+    const int wb = it & 1;             // s_act[wb]: items that change in this round
     bool changed = false;
-    if (has_item) {
-      uint32_t* Ec = E + pitch + c + 1;  // Ec[r * pitch] = E(r, c)
-      auto Cat = [&](int r) -> uint32_t { return C_IN_LDS ? Cl[r * wpr + c] : cs[r * wpr + c].x; };
-      // down
-      uint32_t prev_d = dil3(Ec[(r0 - 1) * pitch], Ec[(r0 - 1) * pitch - 1], Ec[(r0 - 1) * pitch + 1]);
+    if (tid < n_list) {
+      const int item = it == 0 ? tid : (int)s_list[tid];
+      const int strip = item / wpr, c = item - strip * wpr;
+      const int r0 = strip * rpt, r1 = min(h, r0 + rpt) - 1;
+      uint32_t* Ec = E + pitch + c;  // Ec[r * pitch] = E(r, c); the words left of column 0 / right of the last one are masked
+      const uint32_t lm = c > 0 ? ~0u : 0u, rm = c < wpr - 1 ? ~0u : 0u;
+      auto Cat = [&](int r) -> uint32_t { return C_IN_LDS ? (Cl[r * wpr + c] | Ec[r * pitch]) : cs[r * wpr + c].x; };
+      // down: the row above is already final for this sweep, the row below still has last round's bits
+      uint32_t prev_d = dil3(Ec[(r0 - 1) * pitch], Ec[(r0 - 1) * pitch - 1] & lm, Ec[(r0 - 1) * pitch + 1] & rm);
+      uint32_t cur = Ec[r0 * pitch], cl = Ec[r0 * pitch - 1] & lm, cr = Ec[r0 * pitch + 1] & rm;
       for (int r = r0; r <= r1; ++r) {
-        const uint32_t cur = Ec[r * pitch], cl = Ec[r * pitch - 1], cr = Ec[r * pitch + 1];
-        const uint32_t nd = dil3(Ec[(r + 1) * pitch], Ec[(r + 1) * pitch - 1], Ec[(r + 1) * pitch + 1]);
+        const uint32_t nx = Ec[(r + 1) * pitch], nl = Ec[(r + 1) * pitch - 1] & lm, nr = Ec[(r + 1) * pitch + 1] & rm;
         const uint32_t Cw = Cat(r);
         const uint32_t hz = __builtin_amdgcn_alignbit(cur, cl, 31) | __builtin_amdgcn_alignbit(cr, cur, 1);
-        const uint32_t F = run_fill(Cw, cur | (Cw & (prev_d | nd | hz)));
+        const uint32_t F = run_fill(Cw, cur | (Cw & (prev_d | dil3(nx, nl, nr) | hz)));
         if (F != cur) { Ec[r * pitch] = F; changed = true; }
         prev_d = dil3(F, cl, cr);
+        cur = nx; cl = nl; cr = nr;
       }
       // up
-      prev_d = dil3(Ec[(r1 + 1) * pitch], Ec[(r1 + 1) * pitch - 1], Ec[(r1 + 1) * pitch + 1]);
+      prev_d = dil3(cur, cl, cr);  // row r1 + 1, just loaded
+      cur = Ec[r1 * pitch]; cl = Ec[r1 * pitch - 1] & lm; cr = Ec[r1 * pitch + 1] & rm;
       for (int r = r1; r >= r0; --r) {
-        const uint32_t cur = Ec[r * pitch], cl = Ec[r * pitch - 1], cr = Ec[r * pitch + 1];
-        const uint32_t nd = dil3(Ec[(r - 1) * pitch], Ec[(r - 1) * pitch - 1], Ec[(r - 1) * pitch + 1]);
+        const uint32_t nx = Ec[(r - 1) * pitch], nl = Ec[(r - 1) * pitch - 1] & lm, nr = Ec[(r - 1) * pitch + 1] & rm;
         const uint32_t Cw = Cat(r);
         const uint32_t hz = __builtin_amdgcn_alignbit(cur, cl, 31) | __builtin_amdgcn_alignbit(cr, cur, 1);
-        const uint32_t F = run_fill(Cw, cur | (Cw & (prev_d | nd | hz)));
+        const uint32_t F = run_fill(Cw, cur | (Cw & (prev_d | dil3(nx, nl, nr) | hz)));
         if (F != cur) { Ec[r * pitch] = F; changed = true; }
         prev_d = dil3(F, cl, cr);
+        cur = nx; cl = nl; cr = nr;
       }
+      if (changed) s_act[wb][item] = 1;
     }
-    // three flags in rotation: the one reset here is written again only after the NEXT barrier and was last
-    // read before THIS one
-    if (changed) s_changed[it % 3] = 1;
+    if (!__syncthreads_or(changed ? 1 : 0)) break;  // nothing changed anywhere: the fixpoint
+    // next round's work list: the items with a changed item in their 3x3 neighbourhood
+    bool act = false;
+    if (tid < n_items) {
+      const int strip = tid / wpr, c = tid - strip * wpr;
+      const unsigned char* a = s_act[wb];
+#pragma unroll
+      for (int ds = -1; ds <= 1; ++ds)
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+          const int ss = strip + ds, cc = c + dc;
+          if (ss >= 0 && ss < nstrips && cc >= 0 && cc < wpr) act = act || a[ss * wpr + cc] != 0;
+        }
+    }
+    const unsigned long long m = __ballot(act);
+    int base = 0;
+    if ((tid & 63) == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+    base = __shfl(base, 0);
+    if (act) s_list[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)tid;
+    s_act[wb ^ 1][tid] = 0;  // the buffer the next round writes
     __syncthreads();
-    const bool any = s_changed[it % 3] != 0;
-    if (tid == 0) s_changed[(it + 2) % 3] = 0;
-    if (!any) break;
+    n_list = s_n;
+    __syncthreads();
+    if (tid == 0) s_n = 0;
   }
   __syncthreads();
+  }
+  __syncthreads();
+  HP(5);
   // edgesPyr / edgesOrigPyr: 16 pixels per store
   uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
   uint8_t* orig = lv.has_orig ? pl.edges_orig[l] + (size_t)f * lv.npix : nullptr;
+  const bool rows16 = (w & 15) == 0;  // then a group of 16 pixels lies in one row and one half of a bitmap word
+  const float inv_w = 1.0f / (float)w;
   for (int i = tid; i < lv.npix / 16; i += HYST_THREADS) {
     const int p = i * 16;
-    const int y = p / w, x = p - y * w;  // w is a multiple of 4, npix of 16: a group may wrap into the next row
+    int y = (int)(((float)p + 0.5f) * inv_w);  // p / w without the integer division ...
+    y += (y + 1) * w <= p ? 1 : (y * w > p ? -1 : 0);  // ... and exact whatever the rounding did
+    const int x = p - y * w;
     uint32_t o[4];
+    if (rows16) {
+      const uint32_t bits = (E[(y + 1) * pitch + (x >> 5)] >> (x & 31)) & 0xffffu;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int xx = x + 4 * q, yy = y;
-      if (xx >= w) { xx -= w; yy += 1; }  // (w >= 16 is not guaranteed: at most one wrap per 4-pixel step is)
-      while (xx >= w) { xx -= w; yy += 1; }
-      const uint32_t bits = (E[(yy + 1) * pitch + (xx >> 5) + 1] >> (xx & 31)) & 0xfu;
-      o[q] = ((bits * 0x00204081u) & 0x01010101u) * 0xffu;
+      for (int q = 0; q < 4; ++q) o[q] = ((((bits >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+    } else {  // w is a multiple of 4, npix of 16: a group may wrap into the next row(s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int xx = x + 4 * q, yy = y;
+        while (xx >= w) { xx -= w; yy += 1; }
+        const uint32_t bits = (E[(yy + 1) * pitch + (xx >> 5)] >> (xx & 31)) & 0xfu;
+        o[q] = ((bits * 0x00204081u) & 0x01010101u) * 0xffu;
+      }
     }
     const uint4 v = make_uint4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<uint4*>(edges + p) = v;
     if (orig) *reinterpret_cast<uint4*>(orig + p) = v;
   }
+  HP(6);
   // histPyr[l] and the number of non-empty tiles (imgpyramidrgbd.cpp:146-172)
   if (lv.patch > 0) {
     const int ntiles = lv.hist_w * lv.hist_h;
     int nz = 0;
+    const float inv_hw = 1.0f / (float)lv.hist_w;
     for (int t0 = 0; t0 < ntiles; t0 += HYST_THREADS) {
       const int t = t0 + tid;
-      int cnt = 0;
       if (t < ntiles) {
-        const int ty = t / lv.hist_w, tx = t - ty * lv.hist_w;
+        int ty = (int)(((float)t + 0.5f) * inv_hw);
+        ty += (ty + 1) * lv.hist_w <= t ? 1 : (ty * lv.hist_w > t ? -1 : 0);
+        const int tx = t - ty * lv.hist_w;
         const int xa = tx * lv.patch, xb = xa + lv.patch;  // [xa, xb)
-        const int wa = xa >> 5, wb = (xb - 1) >> 5;
-        for (int y = ty * lv.patch; y < (ty + 1) * lv.patch; ++y) {
-          const uint32_t* row = E + (y + 1) * pitch + 1;
-          for (int ww = wa; ww <= wb; ++ww) {
-            uint32_t m = row[ww];
-            if (ww == wa) m &= ~0u << (xa & 31);
-            if (ww == wb && (xb & 31)) m &= ~0u >> (32 - (xb & 31));
-            cnt += __popc(m);
-          }
-        }
+        const int wa = xa >> 5, wb = (xb - 1) >> 5;        // patch <= 64: at most 3 words
+        const uint32_t ma = ~0u << (xa & 31), mb = (xb & 31) ? ~0u >> (32 - (xb & 31)) : ~0u;
+        const uint32_t m0 = wa == wb ? ma & mb : ma, m1 = wb > wa + 1 ? ~0u : (wb > wa ? mb : 0u), m2 = wb > wa + 1 ? mb : 0u;
+        const int o1 = wb > wa ? 1 : 0, o2 = wb > wa + 1 ? 2 : 0;
+        const uint32_t* row = E + (ty * lv.patch + 1) * pitch + wa;
+        int cnt = 0;
+        for (int y = 0; y < lv.patch; ++y, row += pitch) cnt += __popc(row[0] & m0) + __popc(row[o1] & m1) + __popc(row[o2] & m2);
         const uint8_t v = (uint8_t)(cnt & 255);
         pl.hist[l][(size_t)f * ntiles + t] = v;
         nz += v != 0;
@@ -463,6 +645,12 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
     __syncthreads();
     if (tid == 0) pl.hist_nz[f * REVO_L + l] = s_nz;
   }
+#ifdef REVO_HYST_PROFILE
+  HP(7);
+  if (threadIdx.x == 0 && l == 0 && f < 12)
+    printf("hyst f=%d: load %lld scan %lld link %lld flag %lld resolve %lld out %lld hist %lld cycles\n", f, hp[1] - hp[0], hp[2] - hp[1],
+           hp[3] - hp[2], hp[4] - hp[3], hp[5] - hp[4], hp[6] - hp[5], hp[7] - hp[6]);
+#endif
 }
 
 // a7: fillInEdges (imgpyramidrgbd.cpp:111-145, gate 188-195).  Level l reads
@@ -911,18 +1099,19 @@ void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   size_t e_bytes = 0, ec_bytes = 0;
   for (int l = 0; l < g.n_levels; ++l) {
-    const size_t e = (size_t)(g.lv[l].h + 2) * (g.lv[l].wpr + 2) * 4, c = (size_t)g.lv[l].h * g.lv[l].wpr * 4;
+    const size_t nw = (size_t)g.lv[l].h * g.lv[l].wpr;
+    const size_t e = ((size_t)(g.lv[l].h + 2) * g.lv[l].wpr + 2) * 4, c = (nw + (nw + 1) / 2) * 4;  // + candidate words + id bases
     e_bytes = e > e_bytes ? e : e_bytes;
     ec_bytes = e + c > ec_bytes ? e + c : ec_bytes;
   }
   static bool attr_set = false;
   if (!attr_set) {  // more than the default 64 KB of dynamic LDS
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<true>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<false>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<true>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<false>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
     attr_set = true;
   }
-  if (ec_bytes <= REVO_HYST_LDS_MAX)
-    hipLaunchKernelGGL(k_hyst<true>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), ec_bytes, s, g, p);
+  if (ec_bytes + 4096 <= REVO_HYST_LDS_MAX)  // candidate bitmap + union-find labels in LDS: all of it (one workgroup per CU anyway)
+    hipLaunchKernelGGL(k_hyst<true>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p);
   else  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
     hipLaunchKernelGGL(k_hyst<false>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), e_bytes, s, g, p);
 }
