@@ -337,15 +337,19 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
 
 #ifdef REVO_HYST_PROFILE
 #define HP(i) if (threadIdx.x == 0) hp[i] = clock64()
+#define HA(i) if (threadIdx.x == 0) { const long long now_ = clock64(); ha[i] += now_ - hlast; hlast = now_; }
 #else
 #define HP(i)
+#define HA(i)
 #endif
 template <bool C_IN_LDS>
 __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl) {
   extern __shared__ uint32_t s_mem[];
 #ifdef REVO_HYST_PROFILE
-  long long hp[12];
+  long long hp[12], ha[8], hlast = 0;
   for (int i = 0; i < 12; ++i) hp[i] = 0;
+  for (int i = 0; i < 8; ++i) ha[i] = 0;
+  int dbg_sweeps = 0, dbg_bands = 0;
 #endif
   HP(0);
   const int f = g.frame0 + blockIdx.z;
@@ -378,126 +382,180 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
   // by neighbouring lanes instead of queueing in one.  If the level has more runs than LDS can label, or its
   // candidate bitmap is not in LDS (big levels), the flood fill below does the job.
   bool done = false;
+#ifdef REVO_HYST_PROFILE
+  int dbg_runs = -1;
+#endif
   if (C_IN_LDS) {
     const int nwords = h * wpr;
-    unsigned short* Bs = reinterpret_cast<unsigned short*>(Cl + nwords);                // runs before word i
-    uint32_t* parent = Cl + nwords + (nwords + 1) / 2;
-    const int cap = (int)(REVO_HYST_LDS_MAX / 4) - (e_words + nwords + (nwords + 1) / 2);  // ids that fit
+    unsigned short* Bs = reinterpret_cast<unsigned short*>(Cl + nwords);          // runs before word i (nwords + 1 entries)
+    uint32_t* parent = Cl + nwords + (nwords + 2) / 2;
+    const int cap = ((int)(REVO_HYST_LDS_MAX / 4) - (e_words + nwords + (nwords + 2) / 2)) / 2;  // runs that fit (parent + rec)
     __shared__ int s_wsum[HYST_THREADS / 64];
-    __shared__ int s_total;
+    __shared__ int s_total, s_promoted;
     auto weak = [&](int wi) -> uint32_t { return Cl[wi]; };
-    auto starts = [](uint32_t wk) -> uint32_t { return wk & ~(wk << 1); };               // first pixel of every run
-    // ids: exclusive prefix of the run counts (contiguous chunks -> wave scan -> 16 wave totals)
-    {
-      const int wpt = (nwords + HYST_THREADS - 1) / HYST_THREADS;
-      const int w0 = min(nwords, tid * wpt), w1 = min(nwords, w0 + wpt);
-      int mine = 0;
-      for (int wi = w0; wi < w1; ++wi) mine += __popc(starts(weak(wi)));
-      int incl = mine;
+    auto starts = [](uint32_t wk) -> uint32_t { return wk & ~(wk << 1); };         // first pixel of every run
+    const float inv_wpr = 1.0f / (float)wpr;
+    const uint32_t FLAG = 0x80000000u, IDM = 0x7fffffffu;
+    // A level whose runs do not fit the label space is cut into bands of rows that do; a band is closed exactly
+    // (its promoted pixels join E, i.e. become seeds for the bands below, closed later in the same sweep) and the
+    // bands are swept again only if a band promoted pixels in its first row, next to a band closed before it --
+    // normally there is one band and one sweep.
+#ifdef REVO_HYST_PROFILE
+    hlast = clock64();
+#endif
+    for (int sweep = 0; sweep < 64 && !done; ++sweep) {
+#ifdef REVO_HYST_PROFILE
+      ++dbg_sweeps;
+#endif
+      // ids: exclusive prefix of the run counts (contiguous chunks -> wave scan -> 16 wave totals)
+      {
+        const int wpt = (nwords + HYST_THREADS - 1) / HYST_THREADS;
+        const int w0 = min(nwords, tid * wpt), w1 = min(nwords, w0 + wpt);
+        int mine = 0;
+        for (int wi = w0; wi < w1; ++wi) mine += __popc(starts(weak(wi)));
+        int incl = mine;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += v;
-      }
-      if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-      __syncthreads();
-      int before = incl - mine;
-      for (int k = 0; k < (tid >> 6); ++k) before += s_wsum[k];
-      if (tid == HYST_THREADS - 1) s_total = before + mine;
-      for (int wi = w0; wi < w1; ++wi) {
-        Bs[wi] = (unsigned short)before;
-        before += __popc(starts(weak(wi)));
-      }
-      __syncthreads();
-    }
-    const int nruns = s_total;
-    HP(2);
-    if (nruns <= cap / 2 && nruns < 65536) {
-      done = true;
-      const uint32_t FLAG = 0x80000000u, IDM = 0x7fffffffu;
-      uint32_t* rec = parent + nruns;  // run -> (word << 5 | first bit): the phases below deal RUNS to the threads
-      // id of the run that holds pixel `bit` of word wi
-      auto id_of = [&](int wi, int bit) -> int { return (int)Bs[wi] + __popc(starts(weak(wi)) & ((2u << bit) - 1u)) - 1; };
-      auto find = [&](int x) -> int {
-        int p = (int)(parent[x] & IDM);
-        while (p != x) {
-          const int gp = (int)(parent[p] & IDM);
-          if (gp != p) atomicMin(&parent[x], (uint32_t)gp);  // path halving (parents only ever decrease)
-          x = p; p = gp;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o);
+          if ((tid & 63) >= o) incl += v;
         }
-        return x;
-      };
-      auto unite = [&](int a2, int b2) {
-        for (;;) {
-          a2 = find(a2); b2 = find(b2);
-          if (a2 == b2) return;
-          if (a2 > b2) { const int t2 = a2; a2 = b2; b2 = t2; }
-          const uint32_t old = atomicMin(&parent[b2], (uint32_t)a2);
-          if ((int)old == b2) return;
-          b2 = (int)old;  // b2 was re-parented meanwhile: keep that link by uniting with it too
+        __syncthreads();  // (s_wsum / s_total of the previous sweep are no longer read)
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        if (tid == 0) s_promoted = 0;
+        __syncthreads();
+        int before = incl - mine;
+        for (int k = 0; k < (tid >> 6); ++k) before += s_wsum[k];
+        if (tid == HYST_THREADS - 1) { s_total = before + mine; Bs[nwords] = (unsigned short)min(65535, before + mine); }
+        for (int wi = w0; wi < w1; ++wi) {
+          Bs[wi] = (unsigned short)before;
+          before += __popc(starts(weak(wi)));
         }
-      };
-      for (int wi = tid; wi < nwords; wi += HYST_THREADS) {
-        int me = Bs[wi];
-        for (uint32_t m = starts(weak(wi)); m; m &= m - 1, ++me) {
-          parent[me] = (uint32_t)me;
-          rec[me] = ((uint32_t)wi << 5) | (uint32_t)(__ffs(m) - 1);
+        __syncthreads();
+      }
+      const int nruns = s_total;
+      HA(0);
+#ifdef REVO_HYST_PROFILE
+      if (sweep == 0) dbg_runs = nruns;
+#endif
+      if (nruns >= 65536 || cap < 64) break;  // ids are 16 bit: leave it to the flood fill
+      if (nruns == 0) { done = true; break; }
+      // bands of equal height whose runs all fit
+      int nb = (nruns + cap - 1) / cap, band_rows = h;
+      for (;; ++nb) {
+        band_rows = (h + nb - 1) / nb;
+        bool fits = true;
+        for (int r0 = 0; r0 < h; r0 += band_rows)
+          fits = fits && ((int)Bs[min(h, r0 + band_rows) * wpr] - (int)Bs[r0 * wpr] <= cap);
+        if (fits || band_rows == 1) break;
+      }
+      if (band_rows == 1 && nb > h) break;  // a single row beyond the label space: flood fill
+      for (int r0 = 0; r0 < h; r0 += band_rows) {
+        const int wa = r0 * wpr, wb = min(h, r0 + band_rows) * wpr;
+        const int id0 = Bs[wa], nr = (int)Bs[wb] - id0;
+        if (nr == 0) continue;
+        uint32_t* rec = parent + nr;  // run -> (word << 5 | first bit): the phases below deal RUNS to the threads
+        // local id of the run that holds pixel `bit` of word wi (wi inside the band)
+        auto id_of = [&](int wi, int bit) -> int { return (int)Bs[wi] - id0 + __popc(starts(weak(wi)) & ((2u << bit) - 1u)) - 1; };
+        // Parents are KEYS, hash15(id) << 16 | id: a root hangs under the root with the smaller key, i.e. under a
+        // pseudo-random one.  Linking by raster-order id turns a vertical chain of n runs that unite concurrently
+        // into a linked list of n hops (200k cycles per level on the low-contrast bench frames); random linking keeps
+        // the expected depth logarithmic, and keys still only ever decrease along a path, so atomicMin halving holds.
+        auto key_of = [](int x) -> uint32_t { return ((((uint32_t)x * 40503u) >> 1) & 0x7fffu) << 16 | (uint32_t)x; };
+        auto find = [&](int x) -> int {
+          uint32_t p2 = parent[x] & IDM;
+          while ((int)(p2 & 0xffffu) != x) {
+            const uint32_t gp = parent[p2 & 0xffffu] & IDM;
+            if (gp != p2) atomicMin(&parent[x], gp);  // path halving (keys only ever decrease along a path)
+            x = (int)(p2 & 0xffffu); p2 = gp;
+          }
+          return x;
+        };
+        auto unite = [&](int a2, int b2) {
+          for (;;) {
+            a2 = find(a2); b2 = find(b2);
+            if (a2 == b2) return;
+            uint32_t ka = key_of(a2), kb = key_of(b2);
+            if (ka > kb) { const int t2 = a2; a2 = b2; b2 = t2; const uint32_t t3 = ka; ka = kb; kb = t3; }
+            const uint32_t old = atomicMin(&parent[b2], ka);
+            if (old == kb) return;
+            b2 = (int)(old & 0xffffu);  // b2 was re-parented meanwhile: keep that link by uniting with it too
+          }
+        };
+        auto run_at = [&](int i, int* wi_out, uint32_t* run_out) {  // rec: word << 10 | first bit << 5 | length - 1
+          const uint32_t rc = rec[i];
+          *wi_out = (int)(rc >> 10);
+          *run_out = (0xffffffffu >> (31u - (rc & 31u))) << ((rc >> 5) & 31u);
+        };
+        for (int wi = wa + tid; wi < wb; wi += HYST_THREADS) {
+          int me = (int)Bs[wi] - id0;
+          const uint32_t wk = weak(wi);
+          for (uint32_t m = starts(wk); m; m &= m - 1, ++me) {
+            const int bit = __ffs(m) - 1;
+            const uint32_t t2 = ~(wk >> bit);  // first zero above the run's first pixel
+            const int len = t2 ? __ffs(t2) - 1 : 32 - bit;
+            parent[me] = key_of(me);
+            rec[me] = ((uint32_t)wi << 10) | ((uint32_t)bit << 5) | (uint32_t)(len - 1);
+          }
         }
-      }
-      __syncthreads();
-      const float inv_wpr = 1.0f / (float)wpr;
-      auto run_at = [&](int i, int* wi_out, uint32_t* run_out) {
-        const uint32_t rc = rec[i];
-        const int wi = (int)(rc >> 5), bit = (int)(rc & 31u);
-        const uint32_t t2 = ~(weak(wi) >> bit);                    // first zero above the run's first pixel
-        const int len = t2 ? __ffs(t2) - 1 : 32 - bit;
-        *wi_out = wi;
-        *run_out = (len >= 32 ? ~0u : ((1u << len) - 1u)) << bit;
-      };
-      // links: the run continuing from the previous word; the runs of the row above that touch this one
-      for (int me = tid; me < nruns; me += HYST_THREADS) {
-        int wi; uint32_t run;
-        run_at(me, &wi, &run);
-        int r = (int)(((float)wi + 0.5f) * inv_wpr);
-        r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
-        const int c = wi - r * wpr;
-        if ((run & 1u) && c > 0 && (weak(wi - 1) >> 31)) unite(me, id_of(wi - 1, 31));
-        if (r == 0) continue;
-        for (uint32_t a2 = weak(wi - wpr) & (run | (run << 1) | (run >> 1)); a2;) {  // one union per run above
-          const int ab = __ffs(a2) - 1;
-          a2 &= ~(a2 & ~(a2 + (1u << ab)));
-          unite(me, id_of(wi - wpr, ab));
+        __syncthreads();
+        HA(1);
+#ifdef REVO_HYST_PROFILE
+        ++dbg_bands;
+#endif
+        // links: the run continuing from the previous word; the runs of the row above (inside the band) that touch this one
+        for (int me = tid; me < nr; me += HYST_THREADS) {
+          int wi; uint32_t run;
+          run_at(me, &wi, &run);
+          int r = (int)(((float)wi + 0.5f) * inv_wpr);
+          r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
+          const int c = wi - r * wpr;
+          if ((run & 1u) && c > 0 && (weak(wi - 1) >> 31)) unite(me, id_of(wi - 1, 31));
+          if (r == r0) continue;
+          for (uint32_t a2 = weak(wi - wpr) & (run | (run << 1) | (run >> 1)); a2;) {  // one union per run above
+            const int ab = __ffs(a2) - 1;
+            a2 &= ~(a2 & ~(a2 + (1u << ab)));
+            unite(me, id_of(wi - wpr, ab));
+          }
+          if ((run & 1u) && c > 0 && (weak(wi - wpr - 1) >> 31)) unite(me, id_of(wi - wpr - 1, 31));
+          if ((run >> 31) && c < wpr - 1 && (weak(wi - wpr + 1) & 1u)) unite(me, id_of(wi - wpr + 1, 0));
         }
-        if ((run & 1u) && c > 0 && (weak(wi - wpr - 1) >> 31)) unite(me, id_of(wi - wpr - 1, 31));
-        if ((run >> 31) && c < wpr - 1 && (weak(wi - wpr + 1) & 1u)) unite(me, id_of(wi - wpr + 1, 0));
+        __syncthreads();
+        HA(2);
+        // every run straight under its root (concurrent path halving flattens a list in ~log steps)
+        for (int me = tid; me < nr; me += HYST_THREADS) parent[me] = key_of(find(me));
+        __syncthreads();
+        HA(3);
+        // components that touch an edge pixel (strong, or promoted in another band): flag the root
+        for (int me = tid; me < nr; me += HYST_THREADS) {
+          int wi; uint32_t run;
+          run_at(me, &wi, &run);
+          int r = (int)(((float)wi + 0.5f) * inv_wpr);
+          r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
+          const int c = wi - r * wpr;
+          const uint32_t lm = c > 0 ? ~0u : 0u, rm = c < wpr - 1 ? ~0u : 0u;
+          const uint32_t* Ec = E + pitch + wi;
+          const uint32_t sd = dil3(Ec[-pitch], Ec[-pitch - 1] & lm, Ec[-pitch + 1] & rm) | dil3(Ec[pitch], Ec[pitch - 1] & lm, Ec[pitch + 1] & rm) |
+                              __builtin_amdgcn_alignbit(Ec[0], Ec[-1] & lm, 31) | __builtin_amdgcn_alignbit(Ec[1] & rm, Ec[0], 1);
+          if (run & sd) atomicOr(&parent[find(me)], FLAG);
+        }
+        __syncthreads();
+        HA(4);
+        // a weak run is an edge iff its root is flagged: it moves from the weak bitmap to E
+        bool any = false;
+        for (int me = tid; me < nr; me += HYST_THREADS) {
+          if (!(parent[parent[me] & 0xffffu] & FLAG)) continue;  // parent[me] is the root's key since the flattening pass
+          int wi; uint32_t run;
+          run_at(me, &wi, &run);
+          atomicOr(&E[pitch + wi], run);
+          atomicAnd(&Cl[wi], ~run);
+          // a promotion can only reach a band that this sweep has ALREADY closed through the band's first row
+          any = any || (r0 > 0 && wi < wa + wpr);
+        }
+        if (any) s_promoted = 1;
+        __syncthreads();
+        HA(5);
       }
-      __syncthreads();
-      // every run straight under its root (concurrent path halving flattens a list in ~log steps)
-      for (int me = tid; me < nruns; me += HYST_THREADS) parent[me] = (uint32_t)find(me);
-      __syncthreads();
-      HP(3);
-      // components that touch a strong pixel: flag the root
-      for (int me = tid; me < nruns; me += HYST_THREADS) {
-        int wi; uint32_t run;
-        run_at(me, &wi, &run);
-        int r = (int)(((float)wi + 0.5f) * inv_wpr);
-        r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
-        const int c = wi - r * wpr;
-        const uint32_t lm = c > 0 ? ~0u : 0u, rm = c < wpr - 1 ? ~0u : 0u;
-        const uint32_t* Ec = E + pitch + wi;  // strong pixels (E is still the seed bitmap)
-        const uint32_t sd = dil3(Ec[-pitch], Ec[-pitch - 1] & lm, Ec[-pitch + 1] & rm) | dil3(Ec[pitch], Ec[pitch - 1] & lm, Ec[pitch + 1] & rm) |
-                            __builtin_amdgcn_alignbit(Ec[0], Ec[-1] & lm, 31) | __builtin_amdgcn_alignbit(Ec[1] & rm, Ec[0], 1);
-        if (run & sd) atomicOr(&parent[find(me)], FLAG);
-      }
-      __syncthreads();
-      HP(4);
-      // a weak run is an edge iff its root is flagged.  E is read as the seed bitmap by nobody any more.
-      for (int me = tid; me < nruns; me += HYST_THREADS) {
-        if (!(parent[find(me)] & FLAG)) continue;
-        int wi; uint32_t run;
-        run_at(me, &wi, &run);
-        atomicOr(&E[pitch + wi], run);
-      }
+      if (nb == 1 || !s_promoted) done = true;
     }
     __syncthreads();
   }
@@ -647,9 +705,9 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
   }
 #ifdef REVO_HYST_PROFILE
   HP(7);
-  if (threadIdx.x == 0 && l == 0 && f < 12)
-    printf("hyst f=%d: load %lld scan %lld link %lld flag %lld resolve %lld out %lld hist %lld cycles\n", f, hp[1] - hp[0], hp[2] - hp[1],
-           hp[3] - hp[2], hp[4] - hp[3], hp[5] - hp[4], hp[6] - hp[5], hp[7] - hp[6]);
+  if (threadIdx.x == 0 && l == 0 && f < 64)
+    printf("hyst f=%d: load %lld uf_total %lld [scan %lld record %lld link %lld compress %lld flag %lld resolve %lld] runs %d sweeps %d bands %d uf %d\n", f,
+           hp[1] - hp[0], hp[5] - hp[1], ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], dbg_runs, dbg_sweeps, dbg_bands, (int)done);
 #endif
 }
 
@@ -1100,7 +1158,7 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   size_t e_bytes = 0, ec_bytes = 0;
   for (int l = 0; l < g.n_levels; ++l) {
     const size_t nw = (size_t)g.lv[l].h * g.lv[l].wpr;
-    const size_t e = ((size_t)(g.lv[l].h + 2) * g.lv[l].wpr + 2) * 4, c = (nw + (nw + 1) / 2) * 4;  // + candidate words + id bases
+    const size_t e = ((size_t)(g.lv[l].h + 2) * g.lv[l].wpr + 2) * 4, c = (nw + (nw + 2) / 2) * 4;  // + candidate words + id bases
     e_bytes = e > e_bytes ? e : e_bytes;
     ec_bytes = e + c > ec_bytes ? e + c : ec_bytes;
   }
