@@ -345,6 +345,47 @@ def main():
         "input_render_s": t_render,
     }
 
+    # ---- the same step fed from HOST memory (revo_track_pairs_submit / _wait): page-locked frames as a decoder
+    # thread would leave them, H2D on its own stream overlapped with the kernels of the previous job.  Reported
+    # next to `value` (which has its inputs resident in HBM); PCIe-bound.
+    if rank == 0 and world == 1:
+        from collections import deque
+        hostb = {}
+        for tag, scale in (("u16", 5000.0), ("f32", None)):
+            fr = []
+            for r in rendered:
+                one = []
+                for kb, kd in ((0, 1), (2, 3)):
+                    d = np.clip(r[kd] * 5000.0, 0, 65535).astype(np.uint16) if scale else r[kd]
+                    one.append((torch.from_numpy(np.ascontiguousarray(r[kb])).pin_memory().numpy(),
+                                torch.from_numpy(np.ascontiguousarray(d)).pin_memory().numpy()))
+                fr.append(tuple(one))
+            hb = api.HostBatchTracker(cam, depth_scale_factor=scale)
+            ref_res = hb.track(fr)  # the records every later job must repeat
+            for j in [hb.submit(fr) for _ in range(3)]:  # warm-up: all three job slots exist before the clock starts
+                hb.wait(j)
+            jobs = deque()
+            k_steps = max(8, a.steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k_steps):
+                jobs.append(hb.submit(fr))
+                if len(jobs) == 3:
+                    last = hb.wait(jobs.popleft())
+            while jobs:
+                last = hb.wait(jobs.popleft())
+            dt_h = time.perf_counter() - t0
+            if any(not (np.array_equal(x["R"], y["R"]) and np.array_equal(x["T"], y["T"])) for x, y in zip(last, ref_res)):
+                raise SystemExit("bench: pipelined host-buffer jobs disagree with the first one")
+            step_bytes = a.pairs * 2 * a.width * a.height * (3 + (2 if scale else 4))
+            hostb[tag] = {"value_incl_h2d": a.pairs * k_steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / k_steps * 1e3,
+                          "h2d_bytes_per_step": step_bytes, "pcie_gbs": step_bytes * k_steps / dt_h / 1e9, "steps": k_steps}
+            del hb
+        hostb["note"] = ("revo_track_pairs_submit/_wait from page-locked host frames, 3 jobs in flight: the H2D of job k+1 overlaps the "
+                         "kernels of job k; u16 = raw depth as on disk (conversion fused into the build), f32 = metres")
+        out["host_buffers"] = hostb
+        out["value_incl_h2d"] = hostb["u16"]["value_incl_h2d"]
+
     # ---- side measurement: ONE sequential stream through the host-buffer API (BASELINE configs[1]
     # stand-in: no TUM data here).  Frame N depends on frame N-1, so this is latency-bound and
     # PCIe-inclusive; it is reported next to, never as, `value`.

@@ -287,6 +287,40 @@ int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT,
                             revo_pair_result* d_results, void* stream, int reps,
                             float* ms_mean);
 
+/* ---- host-buffer batches: what a producer like IOWrapperRGBD::readNextFrame hands over ------------ */
+
+/* One frame-pair in HOST memory, as the reference's producer thread holds it after cv::imread
+ * (iowrapperRGBD.cpp:301-333): BGR8 rows + depth rows (raw uint16 as on disk, or float32 metres after the
+ * reference's convertTo), byte strides like cv::Mat::step.  R_init / T_init: initial pose curr -> ref
+ * (tracker.cpp:286-288), used when use_init != 0 (else identity). */
+typedef struct revo_pair_in {
+  const uint8_t* ref_bgr;   size_t ref_bgr_stride;
+  const void*    ref_depth; size_t ref_depth_stride;
+  const uint8_t* cur_bgr;   size_t cur_bgr_stride;
+  const void*    cur_depth; size_t cur_depth_stride;
+  float R_init[9], T_init[3];
+  int32_t use_init;
+} revo_pair_in;
+typedef revo_pair_result revo_pair_out;
+typedef struct revo_pairs_job revo_pairs_job;
+
+/* n independent frame-pairs from host buffers: upload (H2D on its own stream), both pyramids,
+ * keyframe promotion of the reference frame and TrackerNew::trackFrames per pair, results back to the host.
+ * depth_is_u16 != 0: the depth rows are raw uint16 and depth = raw * (float)(1 / depth_scale_factor) runs inside
+ * the device build (iowrapperRGBD.cpp:326-327).
+ *   revo_track_pairs_submit returns once the inputs have been consumed (the caller may reuse its buffers -- the
+ *   reference's producer does, iowrapperRGBD.h:163), while the device work of this and earlier jobs continues:
+ *   consecutive submits overlap job k+1's PCIe transfer with job k's kernels.  Host memory that is page-locked
+ *   (hipHostMalloc / hipHostRegister / torch pin_memory) is read by DMA at PCIe speed; pageable memory works, slower.
+ *   revo_track_pairs_wait blocks for the job's results (out: n records) and releases it.  A record with flag bit 3
+ *   makes it return REVO_ERR_HIP.  At most 3 jobs may be in flight per context.
+ *   revo_track_pairs = submit + wait. */
+int revo_track_pairs_submit(revo_ctx* ctx, int n, const revo_pair_in* pairs, int depth_is_u16,
+                            double depth_scale_factor, revo_pairs_job** job);
+int revo_track_pairs_wait(revo_pairs_job* job, revo_pair_out* out);
+int revo_track_pairs(revo_ctx* ctx, int n, const revo_pair_in* pairs, int depth_is_u16,
+                     double depth_scale_factor, revo_pair_out* out);
+
 /* ---- REVO::start sequencing (system/system.cpp:84-305) ----------------------- */
 
 /* The reference runs two threads: IOWrapperRGBD::generateImgPyramid builds pyramids into a

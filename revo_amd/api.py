@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import RevoError, check, f32p, i32p, u8p, u16p, vp
-from .settings import (ImgPyramidSettings, OptimizerSettings, TrackerSettings, ResidualInfo, PairResult,
+from .settings import (ImgPyramidSettings, OptimizerSettings, TrackerSettings, ResidualInfo, PairResult, PairIn,
                        MAX_LEVELS, PLANE_GRAY, PLANE_DEPTH, PLANE_EDGES, PLANE_EDGES_ORIG, PLANE_DT,
                        PLANE_GRADTABLE, PLANE_EDGES3D, PLANE_HIST, TRACKER_STATE_OK, TRACKER_STATE_NEW_KF)
 
@@ -351,6 +351,57 @@ class BatchTracker:
         ms = C.c_float()
         check(_lib.lib().revo_batch_time_tracker(self._h, ptr, d_results, stream, reps, C.byref(ms)))
         return ms.value
+
+
+class HostBatchTracker:
+    """n independent frame-pairs from HOST buffers (revo_track_pairs_*): what a producer like
+    IOWrapperRGBD::readNextFrame (iowrapperRGBD.cpp:301-333) holds after decoding -- BGR8 [H,W,3] and depth
+    [H,W] (float32 metres, or raw uint16 + depth_scale_factor) per frame.  submit() returns when the inputs
+    have been read (H2D done) while the kernels of this and earlier jobs continue; wait() returns the
+    records.  Page-locked arrays (e.g. torch pin_memory) are read by DMA at PCIe speed."""
+
+    def __init__(self, cameraPyr, depth_scale_factor=None):
+        self._cam = cameraPyr
+        self.depth_scale_factor = depth_scale_factor
+
+    def _pack(self, pairs, init_RT):
+        n = len(pairs)
+        arr = (PairIn * n)()
+        keep = []
+        want = np.uint16 if self.depth_scale_factor is not None else np.float32
+        for i, (ref, cur) in enumerate(pairs):
+            for name, (bgr, dep) in (("ref", ref), ("cur", cur)):
+                if bgr.dtype != np.uint8 or dep.dtype != want or bgr.strides[-1] != 1 or bgr.strides[-2] != 3 or dep.strides[-1] != dep.itemsize:
+                    raise ValueError("frames must be uint8 BGR [H,W,3] and %s depth [H,W] with contiguous rows" % np.dtype(want).name)
+                keep += [bgr, dep]
+                setattr(arr[i], name + "_bgr", bgr.ctypes.data)
+                setattr(arr[i], name + "_bgr_stride", bgr.strides[0])
+                setattr(arr[i], name + "_depth", dep.ctypes.data)
+                setattr(arr[i], name + "_depth_stride", dep.strides[0])
+            if init_RT is not None:
+                R, T = init_RT[i]
+                arr[i].R_init[:] = _cm3(R).tolist()
+                arr[i].T_init[:] = np.asarray(T, np.float32).tolist()
+                arr[i].use_init = 1
+        return arr, keep
+
+    def submit(self, pairs, init_RT=None):
+        """pairs: list of ((ref_bgr, ref_depth), (cur_bgr, cur_depth)) -> job handle."""
+        arr, keep = self._pack(pairs, init_RT)
+        job = vp()
+        u16 = self.depth_scale_factor is not None
+        check(_lib.lib().revo_track_pairs_submit(self._cam._h, len(pairs), C.cast(arr, vp), int(u16),
+                                                 float(1.0 if self.depth_scale_factor is None else self.depth_scale_factor), C.byref(job)))
+        return (job, len(pairs))
+
+    def wait(self, job):
+        h, n = job
+        out = (PairResult * n)()
+        check(_lib.lib().revo_track_pairs_wait(h, C.cast(out, vp)))
+        return results_from_buffer(bytes(out), n)
+
+    def track(self, pairs, init_RT=None):
+        return self.wait(self.submit(pairs, init_RT))
 
 
 def pack_init_RT(Rs, Ts):

@@ -104,6 +104,10 @@ struct revo_ctx {
   // vote
   std::deque<Past> past;
   int* d_marks; int* d_hist8; int* h_hist8; unsigned* d_vote_done;
+  // host-buffer batches (revo_track_pairs_*): up to 3 jobs in flight, slots recycled per (n, depth type)
+  std::vector<struct revo_pairs_job*> jobs;
+  hipStream_t copy_stream = nullptr, copy_stream2 = nullptr, pair_streams[2] = {nullptr, nullptr};
+  unsigned long long jobs_submitted = 0;
   // coloured point cloud (generateColoredPcl), allocated on first use
   char* d_pcl = nullptr; float* d_pcl_out; uint8_t* d_pcl_clr[2]; int* d_pcl_chunk; unsigned* d_pcl_mask; int* d_pcl_total;
 };
@@ -401,6 +405,9 @@ static void ctx_free(revo_ctx* c) {
   hipSetDevice(c->device);
   if (c->build_stream) hipStreamSynchronize(c->build_stream);
   if (c->stream) hipStreamSynchronize(c->stream);
+  for (int k = 0; k < 2; ++k) if (c->pair_streams[k]) (void)hipStreamDestroy(c->pair_streams[k]);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->copy_stream2) (void)hipStreamDestroy(c->copy_stream2);
   for (auto& p : c->past) { hipFree(p.d_pts); hipFree(p.d_n); }
   for (auto& p : c->past_pool) { hipFree(p.d_pts); hipFree(p.d_n); }
   if (c->build_stream) hipStreamDestroy(c->build_stream);
@@ -414,7 +421,12 @@ static void ctx_free(revo_ctx* c) {
 }
 static void ctx_ref(revo_ctx* c) { c->refs.fetch_add(1); }
 static void ctx_unref(revo_ctx* c) { if (c->refs.fetch_sub(1) == 1) ctx_free(c); }
-extern "C" void revo_ctx_destroy(revo_ctx* c) { if (c) ctx_unref(c); }
+static void pairs_jobs_release(revo_ctx* c);
+extern "C" void revo_ctx_destroy(revo_ctx* c) {
+  if (!c) return;
+  pairs_jobs_release(c);  // the job slots hold batches, and batches hold the context
+  ctx_unref(c);
+}
 // used by revo_vo.hip
 extern "C" void revo_ctx_retain_(revo_ctx* c) { if (c) ctx_ref(c); }
 extern "C" void revo_ctx_release_(revo_ctx* c) { if (c) ctx_unref(c); }
@@ -980,6 +992,161 @@ extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
                     "partial sums in time (device shared with another process?) -- its pose is not valid");
   }
   return REVO_OK;
+}
+
+// ------------------------------------------------------- host-buffer batches --
+struct revo_pairs_job {
+  revo_ctx* ctx = nullptr;
+  int n = 0, is_u16 = 0;
+  bool busy = false;
+  revo_batch* batch = nullptr;
+  uint8_t* d_bgr = nullptr;   // [2n][H][W][3]
+  void* d_depth = nullptr;    // [2n][H][W] f32 or u16
+  revo_pair_result* d_res = nullptr;
+  revo_pair_result* h_res = nullptr;  // pinned
+  float* h_init = nullptr;            // n x 12
+  hipEvent_t ev_h2d = nullptr, ev_h2d2 = nullptr, ev_done = nullptr;
+  hipStream_t stream = nullptr;       // compute stream of the job (alternates, so job k+1's build overlaps job k's tracker)
+};
+
+static void pairs_job_free(revo_pairs_job* j) {
+  if (!j) return;
+  if (j->batch) revo_batch_destroy(j->batch);
+  (void)hipFree(j->d_bgr); (void)hipFree(j->d_depth); (void)hipFree(j->d_res);
+  (void)hipHostFree(j->h_res);
+  delete[] j->h_init;
+  if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
+  if (j->ev_h2d2) (void)hipEventDestroy(j->ev_h2d2);
+  if (j->ev_done) (void)hipEventDestroy(j->ev_done);
+  delete j;
+}
+
+static void pairs_jobs_release(revo_ctx* c) {
+  std::vector<revo_pairs_job*> jobs;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    jobs.swap(c->jobs);
+  }
+  (void)hipSetDevice(c->device);
+  for (revo_pairs_job* j : jobs) {
+    if (j->busy && j->ev_done) (void)hipEventSynchronize(j->ev_done);
+    pairs_job_free(j);
+  }
+}
+
+extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* pairs, int depth_is_u16,
+                                       double depth_scale_factor, revo_pairs_job** job_out) {
+  if (!c || !pairs || !job_out || n <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
+  if (depth_is_u16 && !(depth_scale_factor > 0.0)) return fail(REVO_ERR_INVALID_ARG, "depth_scale_factor must be positive");
+  HIPCHECK(hipSetDevice(c->device));
+  const int w = c->geom.lv[0].w, h = c->geom.lv[0].h;
+  const size_t npix = (size_t)w * h, dsz = depth_is_u16 ? 2 : 4;
+  for (int i = 0; i < n; ++i) {
+    const revo_pair_in& p = pairs[i];
+    if (!p.ref_bgr || !p.ref_depth || !p.cur_bgr || !p.cur_depth) return fail(REVO_ERR_INVALID_ARG, "null image pointer");
+    if (p.ref_bgr_stride < (size_t)w * 3 || p.cur_bgr_stride < (size_t)w * 3 || p.ref_depth_stride < w * dsz || p.cur_depth_stride < w * dsz)
+      return fail(REVO_ERR_INVALID_ARG, "stride smaller than a row");
+  }
+  revo_pairs_job* j = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->copy_stream) {
+      HIPCHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      HIPCHECK(hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
+      HIPCHECK(hipStreamCreateWithFlags(&c->pair_streams[0], hipStreamNonBlocking));
+      HIPCHECK(hipStreamCreateWithFlags(&c->pair_streams[1], hipStreamNonBlocking));
+    }
+    int in_flight = 0;
+    for (revo_pairs_job* q : c->jobs) in_flight += q->busy ? 1 : 0;
+    if (in_flight >= 3) return fail(REVO_ERR_CAPACITY, "three jobs are in flight: call revo_track_pairs_wait first");
+    for (revo_pairs_job* q : c->jobs)
+      if (!q->busy && q->n == n && q->is_u16 == (depth_is_u16 ? 1 : 0)) { j = q; break; }
+    if (!j) {
+      for (size_t k = 0; k < c->jobs.size(); ++k)  // a free slot of another shape makes room (HBM is finite)
+        if (!c->jobs[k]->busy && c->jobs.size() >= 3) { pairs_job_free(c->jobs[k]); c->jobs.erase(c->jobs.begin() + k); break; }
+      j = new revo_pairs_job();
+      j->ctx = c; j->n = n; j->is_u16 = depth_is_u16 ? 1 : 0;
+      struct Guard { revo_pairs_job* j; ~Guard() { if (j) pairs_job_free(j); } } guard{j};
+      int rc = revo_batch_create(c, n, &j->batch);
+      if (rc) return rc;
+      HIPCHECK(hipMalloc((void**)&j->d_bgr, 2 * (size_t)n * npix * 3));
+      HIPCHECK(hipMalloc(&j->d_depth, 2 * (size_t)n * npix * dsz));
+      HIPCHECK(hipMalloc((void**)&j->d_res, sizeof(revo_pair_result) * n));
+      HIPCHECK(hipHostMalloc((void**)&j->h_res, sizeof(revo_pair_result) * n));
+      j->h_init = new float[12 * (size_t)n];
+      HIPCHECK(hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&j->ev_h2d2, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&j->ev_done, hipEventDisableTiming));
+      guard.j = nullptr;
+      c->jobs.push_back(j);
+    }
+    j->busy = true;
+    j->stream = c->pair_streams[c->jobs_submitted++ & 1];
+  }
+  // H2D straight from the caller's rows (no host-side staging copy): one copy per plane (strided only when the
+  // rows are padded), colour planes and depth planes on two streams so that two DMA engines work
+  hipStream_t cs = c->copy_stream, cs2 = c->copy_stream2;
+  bool any_init = false;
+  auto upload = [&](void* dst, const void* src, size_t src_stride, size_t row_bytes, hipStream_t st) -> hipError_t {
+    if (src_stride == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * h, hipMemcpyHostToDevice, st);
+    return hipMemcpy2DAsync(dst, row_bytes, src, src_stride, row_bytes, h, hipMemcpyHostToDevice, st);
+  };
+  for (int i = 0; i < n; ++i) {
+    const revo_pair_in& p = pairs[i];
+    const uint8_t* bs[2] = {p.ref_bgr, p.cur_bgr};
+    const size_t bst[2] = {p.ref_bgr_stride, p.cur_bgr_stride};
+    const void* ds[2] = {p.ref_depth, p.cur_depth};
+    const size_t dst[2] = {p.ref_depth_stride, p.cur_depth_stride};
+    for (int k = 0; k < 2; ++k) {
+      const size_t f = 2 * (size_t)i + k;
+      HIPCHECK(upload(j->d_bgr + f * npix * 3, bs[k], bst[k], (size_t)w * 3, cs));
+      HIPCHECK(upload((char*)j->d_depth + f * npix * dsz, ds[k], dst[k], w * dsz, cs2));
+    }
+    float* q = j->h_init + 12 * (size_t)i;
+    if (p.use_init) { memcpy(q, p.R_init, sizeof(float) * 9); memcpy(q + 9, p.T_init, sizeof(float) * 3); any_init = true; }
+    else { const float I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; memcpy(q, I, sizeof(I)); }
+  }
+  HIPCHECK(hipEventRecord(j->ev_h2d2, cs2));
+  HIPCHECK(hipStreamWaitEvent(cs, j->ev_h2d2, 0));
+  HIPCHECK(hipEventRecord(j->ev_h2d, cs));
+  hipStream_t s = j->stream;
+  HIPCHECK(hipStreamWaitEvent(s, j->ev_h2d, 0));
+  int rc = depth_is_u16 ? revo_batch_build_u16(j->batch, j->d_bgr, (const uint16_t*)j->d_depth, depth_scale_factor, s)
+                        : revo_batch_build(j->batch, j->d_bgr, (const float*)j->d_depth, s);
+  if (!rc) rc = revo_batch_track_only(j->batch, any_init ? j->h_init : nullptr, j->d_res, s);
+  if (rc) { j->busy = false; return rc; }
+  HIPCHECK(hipMemcpyAsync(j->h_res, j->d_res, sizeof(revo_pair_result) * n, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipEventRecord(j->ev_done, s));
+  // the caller's buffers are free again once the DMA has read them; the kernels keep running
+  HIPCHECK(hipEventSynchronize(j->ev_h2d));
+  *job_out = j;
+  return REVO_OK;
+}
+
+extern "C" int revo_track_pairs_wait(revo_pairs_job* j, revo_pair_out* out) {
+  if (!j || !j->busy) return fail(REVO_ERR_INVALID_ARG, "not a job in flight");
+  HIPCHECK(hipSetDevice(j->ctx->device));
+  hipError_t e = hipEventSynchronize(j->ev_done);
+  int rc = REVO_OK;
+  if (e != hipSuccess) rc = fail(REVO_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+  if (!rc) {
+    if (out) memcpy(out, j->h_res, sizeof(revo_pair_result) * j->n);
+    for (int i = 0; i < j->n && !rc; ++i)
+      if (j->h_res[i].flags & 8)
+        rc = fail(REVO_ERR_HIP, "tracker: pair " + std::to_string(i) + ": the workgroups of the pair could not exchange partial sums "
+                  "in time (device shared with another process?) -- its pose is not valid");
+  }
+  std::lock_guard<std::mutex> lk(j->ctx->mu);
+  j->busy = false;
+  return rc;
+}
+
+extern "C" int revo_track_pairs(revo_ctx* c, int n, const revo_pair_in* pairs, int depth_is_u16, double depth_scale_factor,
+                                revo_pair_out* out) {
+  revo_pairs_job* j = nullptr;
+  const int rc = revo_track_pairs_submit(c, n, pairs, depth_is_u16, depth_scale_factor, &j);
+  if (rc) return rc;
+  return revo_track_pairs_wait(j, out);
 }
 
 extern "C" int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out) {

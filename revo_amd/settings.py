@@ -122,3 +122,14 @@ class PairResult(C.Structure):
 
 
 assert C.sizeof(PairResult) == 96
+
+
+class PairIn(C.Structure):
+    """revo_pair_in (include/revo_hip.h): one frame-pair in host memory."""
+    _fields_ = [
+        ("ref_bgr", C.c_void_p), ("ref_bgr_stride", C.c_size_t),
+        ("ref_depth", C.c_void_p), ("ref_depth_stride", C.c_size_t),
+        ("cur_bgr", C.c_void_p), ("cur_bgr_stride", C.c_size_t),
+        ("cur_depth", C.c_void_p), ("cur_depth_stride", C.c_size_t),
+        ("R_init", C.c_float * 9), ("T_init", C.c_float * 3), ("use_init", C.c_int32),
+    ]
