@@ -49,6 +49,19 @@ def usable_cpus():
     return max(1, n)
 
 
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    return model, allowed
+
+
 def render_pair(args):
     seed, w, h, levels = args
     from revo_amd import synth
@@ -345,6 +358,12 @@ def main():
         "input_render_s": t_render,
     }
 
+    # the collective has done its job (and been timed): RCCL's proxy threads must not compete with the host-side
+    # measurements below (IO thread + consumer thread of the sequential stream) for the cgroup's CPUs
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
     # ---- the same step fed from HOST memory (revo_track_pairs_submit / _wait): page-locked frames as a decoder
     # thread would leave them, H2D on its own stream overlapped with the kernels of the previous job.  Reported
     # next to `value` (which has its inputs resident in HBM); PCIe-bound.
@@ -405,24 +424,38 @@ def main():
         dt_seq = min(runs)
         ate_seq = synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
         rpe_t, rpe_r = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
-        cpu_seq = None
-        if a.cpu_baseline != "off":  # the same stream through the oracle's REVO::start restatement, 1 core
+        cpu_seq = cpu_seq_2core = cpu_trk_only = None
+        seq_pinned, seq_passes = None, 0
+        if a.cpu_baseline != "off":  # the same stream through the oracle's REVO::start restatement
             from oracle import ro
+            nseq = min(n, 40)
             ovo = ro.VO(s)
             t0 = time.perf_counter()
-            for fr in stream_frames[: min(n, 40)]:
+            for fr in stream_frames[:nseq]:
                 ovo.push(*fr)
-            cpu_seq = min(n, 40) / (time.perf_counter() - t0)
+            cpu_seq = nseq / (time.perf_counter() - t0)  # everything on one core
             t_pyr, t_kf, t_trk = ovo.times()  # seconds in: pyramid builds, makeKeyframe, tracking + vote
-            # the reference builds pyramids on its IO thread (system.cpp:96): 2-core pipelined rate (derived)
-            cpu_seq_2core = min(n, 40) / max(t_pyr, t_kf + t_trk)
-            cpu_trk_only = min(n, 40) / t_trk
+            cpu_trk_only = nseq / t_trk
+            # the reference's threading (system.cpp:96): IO thread builds pyramids, main thread tracks -- measured,
+            # each thread pinned to its own core, 1 warm-up + 5 passes, median
+            _, allowed = cpu_info()
+            seq_pinned = [allowed[0], allowed[1 % len(allowed)]]
+            sb = np.stack([f[0] for f in stream_frames[:nseq]])
+            sd = np.stack([f[1] for f in stream_frames[:nseq]])
+            st = [f[2] for f in stream_frames[:nseq]]
+            times_seq = []
+            for _ in range(6):
+                times_seq.append(ro.VO(s).run_pipelined(sb, sd, st, seq_pinned[0], seq_pinned[1])[0])
+            seq_passes = len(times_seq) - 1
+            cpu_seq_2core = nseq / float(np.median(times_seq[1:]))
         out["single_stream"] = {"frames_per_s": n / dt_seq, "frames_per_s_runs": [n / t for t in runs], "frames": n,
                                 "keyframes": drv.nKeyFrames,
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
                                 "rpe_rmse_per_frame": {"trans_m": rpe_t, "rot_rad": rpe_r},
                                 "cpu_oracle_frames_per_s_1core": cpu_seq,
-                                "cpu_oracle_frames_per_s_2core_pipelined_derived": cpu_seq_2core if cpu_seq else None,
+                                "cpu_oracle_frames_per_s_2core_pipelined": cpu_seq_2core,
+                                "cpu_oracle_2core": {"pinned_cpus": seq_pinned, "passes": seq_passes, "statistic": "median",
+                                                     "threads": "IO thread (pyramids) + main thread (keyframes, tracking, vote)"},
                                 "cpu_oracle_tracker_only_frames_per_s_1core": cpu_trk_only if cpu_seq else None,
                                 "speedup_vs_cpu_oracle_2core_pipelined": (n / dt_seq / cpu_seq_2core) if cpu_seq else None,
                                 "speedup_vs_cpu_oracle": (n / dt_seq / cpu_seq) if cpu_seq else None,
@@ -430,34 +463,47 @@ def main():
                                         "sweep: host copy + H2D + pyramid on the IO thread, trackFrames + quality vote "
                                         "per frame on the consumer thread (PCIe-inclusive)"}
 
-    # ---- CPU baseline: the oracle (plain-C port, 1 core) on a bounded sample of the same workload
+    # ---- CPU baseline: the oracle (plain-C port of the reference's algorithm) on the same batch
+    # with the reference's thread model -- the IO thread builds the pyramids, the main thread promotes keyframes and
+    # tracks (system.cpp:96) -- each pinned to its own core, 1 warm-up + 5 passes, median.  Bounded: ~0.3 s per pass.
     if rank == 0 and world == 1 and a.cpu_baseline != "off":
         from oracle import ro
-        trk = ro.Tracker(s)
-        done, t0 = 0, time.perf_counter()
-        I3, Z3 = np.eye(3), np.zeros(3)
-        while True:
-            for i in range(a.pairs):
-                o_ref = ro.Pyramid(s, rendered[i][0], rendered[i][1])
-                o_cur = ro.Pyramid(s, rendered[i][2], rendered[i][3])
-                o_ref.makeKeyframe()
-                trk.trackFrames(o_ref, o_cur, I3, Z3)
-                done += 1
-                if time.perf_counter() - t0 > a.cpu_seconds and done >= 8:
-                    break
-            if time.perf_counter() - t0 > a.cpu_seconds and done >= 8:
-                break
-        cpu_t = time.perf_counter() - t0
+        model, allowed = cpu_info()
+        pinned = [allowed[0], allowed[1 % len(allowed)]]
+        passes = ro.bench_pairs_pipelined(s, bgr, dep, pinned[0], pinned[1], 6)
+        med = float(np.median(passes[1:]))
         out["cpu_baseline"] = {
-            "value": done / cpu_t, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frame-pairs of the same batch (2 pyramids + keyframe + trackFrames each), oracle/ "
-                      "plain-C restatement, gcc -O3 -mavx2, 1 thread, %.1f s" % (done, cpu_t),
+            "value": a.pairs / med, "unit": "frames/s", "cores": 2, "kind": "port",
+            "pinned_cpus": pinned, "passes": len(passes) - 1, "warmup_passes": 1, "statistic": "median",
+            "pass_seconds": passes[1:], "cpu_model": model, "nproc": os.cpu_count(), "cpus_allowed": len(allowed),
+            "cpus_granted_by_cgroup": usable_cpus(),
+            "sample": "the %d frame-pairs of the timed batch per pass (2 pyramids + keyframe + trackFrames each), oracle/ "
+                      "plain-C restatement, gcc -O3 -mavx2, IO thread + tracker thread like the reference" % a.pairs,
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        # context: the same port on ALL host hardware threads, one pair per
+        # one core (everything on the tracker's thread), same pinning, 1 warm-up + 3 passes
+        trk = ro.Tracker(s)
+        I3, Z3 = np.eye(3), np.zeros(3)
+        os.sched_setaffinity(0, {pinned[1]})
+        try:
+            one = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                for i in range(a.pairs):
+                    o_ref = ro.Pyramid(s, rendered[i][0], rendered[i][1])
+                    o_cur = ro.Pyramid(s, rendered[i][2], rendered[i][3])
+                    o_ref.makeKeyframe()
+                    trk.trackFrames(o_ref, o_cur, I3, Z3)
+                one.append(time.perf_counter() - t0)
+        finally:
+            os.sched_setaffinity(0, set(allowed))
+        out["cpu_baseline_1core"] = {"value": a.pairs / float(np.median(one[1:])), "unit": "frames/s", "cores": 1, "kind": "port",
+                                     "pinned_cpus": [pinned[1]], "passes": len(one) - 1, "statistic": "median"}
+        out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline_1core"]["value"]
+        # context: the same port on ALL granted hardware threads, one pair per
         # thread at a time (native pthreads inside the oracle library), bounded to a few seconds
         ncore = usable_cpus()
-        total, all_t = ro.bench_pairs_mt(s, bgr, dep, ncore, min(6.0, a.cpu_seconds))
+        total, all_t = ro.bench_pairs_mt(s, bgr, dep, ncore, min(4.0, a.cpu_seconds))
         out["cpu_baseline_all_cores"] = {
             "value": total / all_t, "unit": "frames/s", "cores": ncore, "kind": "port",
             "sample": "%d frame-pairs over %d threads (= CPUs granted by the cgroup quota) in %.1f s, native pthreads, "

@@ -232,6 +232,11 @@ int revo_tracker_assess_quality(revo_ctx* ctx, const float T_w_curr_colmajor[16]
  * tracker.cpp:209-223: pcl = src->return3DEdges(lvl) (kept on the device). */
 int revo_tracker_add_old_pcl(revo_ctx* ctx, const revo_pyr* src, int lvl,
                              const float T_w_colmajor[16], double timestamp);
+/* The same with the cloud in HOST memory, exactly the reference's signature
+ * addOldPclAndPose(const Eigen::MatrixXf& pcl, ...): pcl = 4 x n column-major floats (X,Y,Z,1 per point), copied
+ * (the reference copies the matrix, tracker.cpp:219). */
+int revo_tracker_add_old_pcl_host(revo_ctx* ctx, const float* pcl_4xn_colmajor, size_t n,
+                                  const float T_w_colmajor[16], double timestamp);
 /* void TrackerNew::clearUpPastLists(), tracker.cpp:248-257 */
 int revo_tracker_clear_past(revo_ctx* ctx);
 int revo_tracker_past_size(const revo_ctx* ctx);

@@ -1,3 +1,6 @@
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* pthread_setaffinity_np (CPU baseline by the book) */
+#endif
 /*
  * revo_oracle.c -- CPU ORACLE (test infrastructure only; see revo_oracle.h).
  *
@@ -1200,11 +1203,18 @@ void ro_vo_times(const ro_vo* v, double out3[3]) { out3[0] = v->t_pyr; out3[1] =
 
 static void pose_world(const ro_pose* p, float out[16]) { ro_mat4_mul(p->T_w_kf, p->T_kf_curr, out); }
 
+static int ro_vo_track(ro_vo* v, ro_pyramid* curr, double ts, float pose_out[16]);
 int ro_vo_push(ro_vo* v, const uint8_t* bgr, size_t bgr_stride, const float* depth,
                size_t depth_stride, double ts, float pose_out[16]) {
-  double t0 = now_s();
+  const double t0 = now_s();
   ro_pyramid* curr = ro_pyramid_create(&v->ps, bgr, bgr_stride, depth, depth_stride, ts);
   v->t_pyr += now_s() - t0;
+  return ro_vo_track(v, curr, ts, pose_out);
+}
+
+/* one body of the consumer loop of REVO::start (system.cpp:128-284) on a pyramid the producer built */
+static int ro_vo_track(ro_vo* v, ro_pyramid* curr, double ts, float pose_out[16]) {
+  double t0;
   int new_kf = 0;
   const int hl = v->ts.histogram_level;
   if (v->no_frames == 0) { /* system.cpp:151-175 */
@@ -1336,4 +1346,120 @@ long ro_bench_pairs_mt(const revo_pyr_settings* ps, const revo_opt_settings* os,
   if (elapsed_out) *elapsed_out = now_s() - t0;
   free(th); free(jobs);
   return total;
+}
+
+
+/* ======================================================================== */
+/* The reference's threading: the IO thread builds   */
+/* pyramids into a bounded queue (system.cpp:96, iowrapperRGBD.cpp:279-288), */
+/* the main thread promotes keyframes and tracks.  Each thread is pinned to   */
+/* one CPU (cpu id < 0: not pinned).                                          */
+/* ======================================================================== */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
+typedef struct {
+  pthread_mutex_t mu; pthread_cond_t cv;
+  ro_pyramid** ring; int cap, head, count, closed;
+} ro_queue;
+static void q_init(ro_queue* q, int cap) {
+  pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
+  q->ring = (ro_pyramid**)calloc((size_t)cap, sizeof(ro_pyramid*)); q->cap = cap; q->head = q->count = q->closed = 0;
+}
+static void q_free(ro_queue* q) { free(q->ring); pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv); }
+static void q_push(ro_queue* q, ro_pyramid* p) {
+  pthread_mutex_lock(&q->mu);
+  while (q->count == q->cap) pthread_cond_wait(&q->cv, &q->mu);
+  q->ring[(q->head + q->count++) % q->cap] = p;
+  pthread_cond_broadcast(&q->cv);
+  pthread_mutex_unlock(&q->mu);
+}
+static ro_pyramid* q_pop(ro_queue* q) { /* NULL: closed and drained */
+  pthread_mutex_lock(&q->mu);
+  while (q->count == 0 && !q->closed) pthread_cond_wait(&q->cv, &q->mu);
+  ro_pyramid* p = NULL;
+  if (q->count) { p = q->ring[q->head]; q->head = (q->head + 1) % q->cap; --q->count; }
+  pthread_cond_broadcast(&q->cv);
+  pthread_mutex_unlock(&q->mu);
+  return p;
+}
+static void q_close(ro_queue* q) {
+  pthread_mutex_lock(&q->mu); q->closed = 1; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->mu);
+}
+static void pin_self(int cpu) {
+  if (cpu < 0) return;
+  cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpu, &set);
+  pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+
+typedef struct {
+  const revo_pyr_settings* ps; const uint8_t* bgr; const float* depth; const double* ts;
+  int n_frames, cpu; ro_queue* q;
+} ro_producer;
+static void* ro_producer_main(void* arg) {
+  ro_producer* p = (ro_producer*)arg;
+  pin_self(p->cpu);
+  const int w = p->ps->width, h = p->ps->height;
+  const size_t fb = (size_t)w * h * 3, fd = (size_t)w * h;
+  for (int i = 0; i < p->n_frames; ++i)
+    q_push(p->q, ro_pyramid_create(p->ps, p->bgr + (size_t)i * fb, (size_t)w * 3, p->depth + (size_t)i * fd, (size_t)w * 4,
+                                   p->ts ? p->ts[i] : (double)i));
+  q_close(p->q);
+  return NULL;
+}
+
+/* REVO::start with its IO thread: frames [n][H][W][3] / [n][H][W]; poses_out n x 16 (may be NULL).  Returns the
+ * wall time of the whole stream. */
+double ro_vo_run_pipelined(ro_vo* v, int n_frames, const uint8_t* bgr, const float* depth, const double* ts, int cpu_io,
+                           int cpu_main, int queue_cap, float* poses_out) {
+  ro_queue q; q_init(&q, queue_cap > 0 ? queue_cap : 4);
+  ro_producer prod = {&v->ps, bgr, depth, ts, n_frames, cpu_io, &q};
+  cpu_set_t old; const int have_old = pthread_getaffinity_np(pthread_self(), sizeof(old), &old) == 0;
+  const double t0 = now_s();
+  pthread_t th; pthread_create(&th, NULL, ro_producer_main, &prod);
+  pin_self(cpu_main);
+  int i = 0;
+  for (ro_pyramid* p; (p = q_pop(&q)) != NULL; ++i) {
+    float pose[16];
+    ro_vo_track(v, p, ts ? ts[i] : (double)i, pose);
+    if (poses_out) memcpy(poses_out + 16 * (size_t)i, pose, sizeof(pose));
+  }
+  pthread_join(th, NULL);
+  const double dt = now_s() - t0;
+  if (have_old) pthread_setaffinity_np(pthread_self(), sizeof(old), &old);
+  q_free(&q);
+  return dt;
+}
+
+/* The batch workload (n independent frame-pairs: frames ref, curr, ref, curr, ...) with the same two threads: the IO
+ * thread builds the pyramids, the main thread runs makeKeyframe + trackFrames per pair.  seconds_out[passes]. */
+void ro_bench_pairs_pipelined(const revo_pyr_settings* ps, const revo_opt_settings* os, const revo_tracker_settings* ts,
+                              const uint8_t* bgr, const float* depth, int n_pairs, int cpu_io, int cpu_main, int passes,
+                              double* seconds_out) {
+  cpu_set_t old; const int have_old = pthread_getaffinity_np(pthread_self(), sizeof(old), &old) == 0;
+  ro_tracker* t = ro_tracker_create(ps, os, ts);
+  for (int pass = 0; pass < passes; ++pass) {
+    ro_queue q; q_init(&q, 8);
+    ro_producer prod = {ps, bgr, depth, NULL, 2 * n_pairs, cpu_io, &q};
+    const double t0 = now_s();
+    pthread_t th; pthread_create(&th, NULL, ro_producer_main, &prod);
+    pin_self(cpu_main);
+    for (;;) {
+      ro_pyramid* ref = q_pop(&q);
+      if (!ref) break;
+      ro_pyramid* cur = q_pop(&q);
+      ro_pyramid_make_keyframe(ref);
+      float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0}, err = 0.f;
+      int flags = 0;
+      ro_tracker_track_frames(t, ref, cur, R, T, &err, NULL, NULL, &flags);
+      ro_pyramid_destroy(ref);
+      ro_pyramid_destroy(cur);
+    }
+    pthread_join(th, NULL);
+    seconds_out[pass] = now_s() - t0;
+    q_free(&q);
+  }
+  ro_tracker_destroy(t);
+  if (have_old) pthread_setaffinity_np(pthread_self(), sizeof(old), &old);
 }

@@ -133,6 +133,14 @@ int ro_vo_num_keyframes(const ro_vo* v);
 /* Same sequencing but the pyramid build is skipped in the timing split:
  * cumulative seconds spent in (pyramid build, makeKeyframe, tracking+vote). */
 void ro_vo_times(const ro_vo* v, double out3[3]);
+/* REVO::start with the reference's IO thread (system.cpp:96): producer pinned to cpu_io, consumer (the caller) to
+ * cpu_main (< 0: not pinned); returns the wall time of the stream. */
+double ro_vo_run_pipelined(ro_vo* v, int n_frames, const uint8_t* bgr, const float* depth, const double* ts, int cpu_io,
+                           int cpu_main, int queue_cap, float* poses_out);
+/* n independent frame-pairs with the same two threads; seconds_out[passes] */
+void ro_bench_pairs_pipelined(const revo_pyr_settings* ps, const revo_opt_settings* os, const revo_tracker_settings* ts,
+                              const uint8_t* bgr, const float* depth, int n_pairs, int cpu_io, int cpu_main, int passes,
+                              double* seconds_out);
 
 /* bench.py's all-core CPU baseline: n_threads pthreads, one frame-pair per thread at a time (2 pyramids +
  * makeKeyframe + trackFrames from identity) for `seconds`; frames are packed [ref0,curr0,ref1,...].  Returns

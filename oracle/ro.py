@@ -101,6 +101,12 @@ def lib():
         L.ro_edges3d.argtypes = [u8p, f32p, C.c_int, C.c_int] + [C.c_float] * 6 + [f32p]
         L.ro_u16_to_depth.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, C.c_int, C.c_int, C.c_double, f32p]
         L.ro_set_accum_double.argtypes = [C.c_int]
+        L.ro_vo_run_pipelined.restype = C.c_double
+        L.ro_vo_run_pipelined.argtypes = [C.c_void_p, C.c_int, u8p, f32p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, f32p]
+        L.ro_bench_pairs_pipelined.restype = None
+        L.ro_bench_pairs_pipelined.argtypes = [C.POINTER(ImgPyramidSettings), C.POINTER(OptimizerSettings),
+                                               C.POINTER(TrackerSettings), u8p, f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(C.c_double)]
         L.ro_bench_pairs_mt.restype = C.c_long
         L.ro_bench_pairs_mt.argtypes = [C.POINTER(ImgPyramidSettings), C.POINTER(OptimizerSettings),
                                         C.POINTER(TrackerSettings), u8p, f32p, C.c_int, C.c_int, C.c_double,
@@ -380,6 +386,18 @@ class VO:
         kf = lib().ro_vo_push(self.h, _p(bgr, u8p), w * 3, _p(depth, f32p), w * 4, ts, _p(pose, f32p))
         return pose.reshape(4, 4).T.copy(), kf
 
+    def run_pipelined(self, bgr_frames, depth_frames, timestamps=None, cpu_io=-1, cpu_main=-1, queue_cap=4):
+        """REVO::start with the reference's IO thread (system.cpp:96): pyramids on one pinned core, keyframes +
+        tracking on another.  frames [n,H,W,3] u8 / [n,H,W] f32 -> (wall seconds, poses [n,4,4])."""
+        bgr = np.ascontiguousarray(bgr_frames, np.uint8)
+        dep = np.ascontiguousarray(depth_frames, np.float32)
+        n = bgr.shape[0]
+        ts = np.ascontiguousarray(timestamps if timestamps is not None else np.arange(n), np.float64)
+        poses = np.empty((n, 16), np.float32)
+        dt = lib().ro_vo_run_pipelined(self.h, n, _p(bgr, u8p), _p(dep, f32p), ts.ctypes.data_as(C.POINTER(C.c_double)),
+                                       int(cpu_io), int(cpu_main), int(queue_cap), _p(poses, f32p))
+        return dt, poses.reshape(n, 4, 4).transpose(0, 2, 1).copy()
+
     def num_keyframes(self):
         return lib().ro_vo_num_keyframes(self.h)
 
@@ -387,6 +405,18 @@ class VO:
         out = (C.c_double * 3)()
         lib().ro_vo_times(self.h, out)
         return tuple(out)
+
+
+def bench_pairs_pipelined(ps, bgr_frames, depth_frames, cpu_io, cpu_main, passes, os_=None, ts=None):
+    """The reference's two threads on the batch workload (frames packed [ref0, curr0, ref1, ...]): the IO thread builds
+    pyramids, the main thread runs makeKeyframe + trackFrames; both pinned.  -> seconds per pass."""
+    bgr = np.ascontiguousarray(bgr_frames, np.uint8)
+    dep = np.ascontiguousarray(depth_frames, np.float32)
+    os_, ts = os_ or OptimizerSettings(), ts or TrackerSettings()
+    out = (C.c_double * passes)()
+    lib().ro_bench_pairs_pipelined(C.byref(ps), C.byref(os_), C.byref(ts), _p(bgr, u8p), _p(dep, f32p), bgr.shape[0] // 2,
+                                   int(cpu_io), int(cpu_main), int(passes), out)
+    return [float(x) for x in out]
 
 
 def bench_pairs_mt(ps, bgr_frames, depth_frames, n_threads, seconds, os_=None, ts=None):

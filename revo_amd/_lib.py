@@ -83,6 +83,7 @@ def lib():
                                             C.POINTER(ResidualInfo), i32p]
     L.revo_tracker_assess_quality.argtypes = [vp, f32p, vp, C.POINTER(C.c_int), i32p, i32p]
     L.revo_tracker_add_old_pcl.argtypes = [vp, vp, C.c_int, f32p, C.c_double]
+    L.revo_tracker_add_old_pcl_host.argtypes = [vp, f32p, C.c_size_t, f32p, C.c_double]
     L.revo_tracker_clear_past.argtypes = [vp]
     L.revo_tracker_past_size.argtypes = [vp]
     L.revo_batch_create.argtypes = [vp, C.c_int, vpp]

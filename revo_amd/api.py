@@ -289,6 +289,13 @@ class TrackerNew:
         Mc = _cm4(worldPose)
         check(_lib.lib().revo_tracker_add_old_pcl(self._cam._h, srcFrame._h, lvl, _p(Mc, f32p), float(timeStamp)))
 
+    def addOldPcl(self, pcl, worldPose, timeStamp=0.0):
+        """The reference's own signature, addOldPclAndPose(const Eigen::MatrixXf& pcl, worldPose, timeStamp)
+        (tracker.cpp:209-223): pcl = N x 4 rows (X,Y,Z,1) in host memory (what return3DEdges gives)."""
+        a = np.ascontiguousarray(pcl, np.float32).reshape(-1, 4)
+        Mc = _cm4(worldPose)
+        check(_lib.lib().revo_tracker_add_old_pcl_host(self._cam._h, _p(a, f32p), a.shape[0], _p(Mc, f32p), float(timeStamp)))
+
     def clearUpPastLists(self):
         check(_lib.lib().revo_tracker_clear_past(self._cam._h))
 

@@ -27,8 +27,10 @@ def _load(path):
 def load_dataset_yaml(path):
     """-> (ImgPyramidSettings, io dict)"""
     d = _load(path)
-    width = int(d.get("Camera.width", d.get("width", 640)))
-    height = int(d.get("Camera.height", d.get("height", 480)))
+    # the pyramid's size comes from "width" / "height" (camerapyr.h:51-53; the shipped files do not set them: 640x480);
+    # "Camera.width" / "Camera.height" only size the IO wrapper's images (iowrapperRGBD.h:120-121)
+    width = int(d.get("width", 640))
+    height = int(d.get("height", 480))
     fx = float(d.get("Camera.fx", (width + height) / 2))  # camerapyr.h:56
     s = ImgPyramidSettings(
         width=width, height=height, fx=fx, fy=float(d.get("Camera.fy", fx)),
@@ -41,10 +43,11 @@ def load_dataset_yaml(path):
     io = dict(main_folder=str(d.get("MainFolder", "")),
               datasets=[datasets] if isinstance(datasets, str) else list(datasets),
               associate=str(d.get("ASSOCIATE", "associate.txt")),
-              depth_scale_factor=float(d.get("DEPTH_SCALE_FACTOR", 5000.0)),
+              depth_scale_factor=float(d.get("DEPTH_SCALE_FACTOR", 1000.0)),  # iowrapperRGBD.h:119
+              img_width=int(d.get("Camera.width", 640)), img_height=int(d.get("Camera.height", 480)),
               skip_first_n_frames=int(d.get("SKIP_FIRST_N_FRAMES", 0)),
               read_n_images=int(d.get("READ_N_IMAGES", 100000)),
-              use_depth_timestamp=int(bool(d.get("useDepthTimeStamp", 0))))
+              use_depth_timestamp=int(bool(d.get("useDepthTimeStamp", 1))))  # iowrapperRGBD.h:126
     return s, io
 
 

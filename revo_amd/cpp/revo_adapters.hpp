@@ -9,7 +9,19 @@
 //   OptimizerSettings / Optimizer             system/optimizer.h:42-186
 //   TrackerSettings / TrackerNew              system/tracker.h:31-105
 //
-// No Eigen / OpenCV dependency: matrices are passed as anything with .data()
+// Reference-typed accessors.  A host that has Eigen and OpenCV (the reference does) defines, before including this
+// header,
+//     #define REVO_MATXF Eigen::MatrixXf      // needs resize(rows, cols), data(), cols()
+//     #define REVO_VEC4F Eigen::Vector4f      // 16 bytes
+//     #define REVO_CVMAT cv::Mat              // needs create(rows, cols, type), data, step; CV_8UC1 / CV_32FC1 defined
+// and gets the reference's own signatures (imgpyramidrgbd.h:45-117, tracker.h:69-80):
+//     const Eigen::MatrixXf& return3DEdges(lvl), const Eigen::Vector4f* returnOptimizationStructure(lvl),
+//     const cv::Mat& returnDistTransform / returnEdges / returnOrigEdges / returnDepth / returnGray(lvl),
+//     TrackerNew(const TrackerSettings&, const ImgPyramidSettings&), addOldPclAndPose(const Eigen::MatrixXf&, pose, ts)
+// -- cached host mirrors of the device planes, returned by const reference like the reference's members.
+// tests/cpp/adapter_refshape.cpp compiles them against Eigen / cv shaped stand-ins and static_asserts the types.
+//
+// No Eigen / OpenCV dependency otherwise: matrices are passed as anything with .data()
 // (Eigen::Matrix3f / Vector3f / Matrix4f are column-major, which is what the ABI
 // wants) and images as anything with .data and .step (cv::Mat) or raw pointers.
 // Error behaviour follows the reference: a failing call logs and exit(0)s
@@ -19,6 +31,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <map>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -88,6 +101,26 @@ class CameraPyr {  // camerapyr.h:113-193
   revo_ctx* ctx_ = nullptr;
 };
 
+// host mirrors handed out by return3DEdges(): addOldPclAndPose(matrix, ...) recognises them and copies the cloud on
+// the device instead of uploading it again
+struct MirrorRegistry {
+  std::mutex mu;
+  std::map<const float*, std::pair<revo_pyr*, int>> by_data;
+  static MirrorRegistry& get() { static MirrorRegistry r; return r; }
+  void add(const float* p, revo_pyr* pyr, int lvl) { std::lock_guard<std::mutex> lk(mu); by_data[p] = {pyr, lvl}; }
+  void drop(revo_pyr* pyr) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto it = by_data.begin(); it != by_data.end();) it = (it->second.first == pyr) ? by_data.erase(it) : std::next(it);
+  }
+  bool find(const float* p, revo_pyr** pyr, int* lvl) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = by_data.find(p);
+    if (it == by_data.end()) return false;
+    *pyr = it->second.first; *lvl = it->second.second;
+    return true;
+  }
+};
+
 // ---- ImgPyramidRGBD ---------------------------------------------------------------
 class ImgPyramidRGBD {  // imgpyramidrgbd.h:27-250
  public:
@@ -104,13 +137,55 @@ class ImgPyramidRGBD {  // imgpyramidrgbd.h:27-250
                  const MatDepth& fullResDepth, double timestamp)
       : ImgPyramidRGBD(settings, camPyr, (const uint8_t*)fullResRgb.data, (size_t)fullResRgb.step,
                        (const float*)fullResDepth.data, (size_t)fullResDepth.step, timestamp) {}
-  ~ImgPyramidRGBD() { revo_pyramid_destroy(pyr_); }
+  ~ImgPyramidRGBD() { MirrorRegistry::get().drop(pyr_); revo_pyramid_destroy(pyr_); }
   ImgPyramidRGBD(const ImgPyramidRGBD&) = delete;
   ImgPyramidRGBD& operator=(const ImgPyramidRGBD&) = delete;
 
   void makeKeyframe() { check(revo_pyramid_make_keyframe(pyr_), "makeKeyframe"); }  // imgpyramidrgbd.cpp:231-252
   void prepareKfForStorage() {}                                                      // imgpyramidrgbd.h:156-169 (no-op)
 
+#if defined(REVO_MATXF) && defined(REVO_VEC4F) && defined(REVO_CVMAT)
+  // ---- the reference's accessor signatures (imgpyramidrgbd.h:45-117): host mirrors, filled on first use
+  const REVO_MATXF& return3DEdges(unsigned lvl) const {  // 4 x N, column-major
+    auto& m = slot(m3d_, lvl);
+    if (!m) {
+      const std::vector<float> v = readF(REVO_PLANE_EDGES3D, lvl, 4);
+      m.reset(new REVO_MATXF());
+      m->resize(4, (long)(v.size() / 4));
+      std::copy(v.begin(), v.end(), m->data());
+      MirrorRegistry::get().add(m->data(), pyr_, (int)lvl);
+    }
+    return *m;
+  }
+  const REVO_VEC4F* returnOptimizationStructure(unsigned lvl) const {  // (-dDT/dx, -dDT/dy, DT, 0) per pixel
+    static_assert(sizeof(REVO_VEC4F) == 16, "REVO_VEC4F must be four packed floats");
+    auto& t = slot(tab_, lvl);
+    if (!t) {
+      const std::vector<float> v = readF(REVO_PLANE_GRADTABLE, lvl, 4);  // fails like "optimizationStructure not built!"
+      t.reset(new std::vector<REVO_VEC4F>(v.size() / 4));
+      std::memcpy((void*)t->data(), v.data(), v.size() * sizeof(float));
+    }
+    return t->data();
+  }
+  const REVO_CVMAT& returnDistTransform(unsigned lvl) const { return matF(dt_, REVO_PLANE_DT, lvl); }
+  const REVO_CVMAT& returnDepth(unsigned lvl) const { return matF(depth_, REVO_PLANE_DEPTH, lvl); }
+  const REVO_CVMAT& returnEdges(unsigned lvl) const { return matU8(edges_, REVO_PLANE_EDGES, lvl); }
+  const REVO_CVMAT& returnOrigEdges(unsigned lvl) const { return matU8(orig_, REVO_PLANE_EDGES_ORIG, lvl); }
+  const REVO_CVMAT& returnGray(unsigned lvl) const { return matU8(gray_, REVO_PLANE_GRAY, lvl); }
+  std::vector<float> generateColoredPcl(unsigned lvl, bool densePcl) const {
+    size_t n = 0;
+    check(revo_pyramid_colored_pcl(pyr_, (int)lvl, densePcl ? 1 : 0, nullptr, 0, &n), "generateColoredPcl");
+    std::vector<float> v(n * 8);
+    if (n) check(revo_pyramid_colored_pcl(pyr_, (int)lvl, densePcl ? 1 : 0, v.data(), n, &n), "generateColoredPcl");
+    return v;
+  }
+  template <class MatX>
+  void generateColoredPcl(unsigned lvl, MatX& clrPcl, bool densePcl) const {  // the reference's signature (Eigen::MatrixXf)
+    const std::vector<float> v = generateColoredPcl(lvl, densePcl);
+    clrPcl.resize(8, (long)(v.size() / 8));
+    std::copy(v.begin(), v.end(), clrPcl.data());
+  }
+#else
   // accessors: lazy device->host copies (imgpyramidrgbd.h:45-117)
   std::vector<float> return3DEdges(unsigned lvl) const { return readF(REVO_PLANE_EDGES3D, lvl, 4); }  // 4 x N col-major
   // imgpyramidrgbd.cpp:279-327: 8 x N column-major (X,Y,Z,1,r,g,b,1)
@@ -133,6 +208,7 @@ class ImgPyramidRGBD {  // imgpyramidrgbd.h:27-250
   std::vector<uint8_t> returnEdges(unsigned lvl) const { return readU8(REVO_PLANE_EDGES, lvl); }
   std::vector<uint8_t> returnOrigEdges(unsigned lvl) const { return readU8(REVO_PLANE_EDGES_ORIG, lvl); }
   std::vector<uint8_t> returnGray(unsigned lvl) const { return readU8(REVO_PLANE_GRAY, lvl); }
+#endif
   std::array<float, 9> returnK(unsigned lvl) const {  // column-major 3x3
     const Camera& c = cameraPyr->at((int)lvl);
     return {c.fx, 0, 0, 0, c.fy, 0, c.cx, c.cy, 1};
@@ -166,6 +242,38 @@ class ImgPyramidRGBD {  // imgpyramidrgbd.h:27-250
     if (n) check(revo_pyramid_read(pyr_, what, (int)lvl, v.data(), v.size(), &n), "accessor");
     return v;
   }
+#if defined(REVO_MATXF) && defined(REVO_VEC4F) && defined(REVO_CVMAT)
+  template <class T> using Slots = std::vector<std::unique_ptr<T>>;
+  template <class T> static std::unique_ptr<T>& slot(Slots<T>& v, unsigned lvl) {
+    if (v.size() <= lvl) v.resize(lvl + 1);
+    return v[lvl];
+  }
+  const REVO_CVMAT& matF(Slots<REVO_CVMAT>& v, revo_plane what, unsigned lvl) const {
+    auto& m = slot(v, lvl);
+    if (!m) {
+      const std::vector<float> d = readF(what, lvl, 1);
+      const Camera& c = cameraPyr->at((int)lvl);
+      m.reset(new REVO_CVMAT());
+      m->create((int)c.height, (int)c.width, CV_32FC1);
+      for (size_t y = 0; y < c.height; ++y) std::memcpy(m->data + y * (size_t)m->step, d.data() + y * c.width, c.width * sizeof(float));
+    }
+    return *m;
+  }
+  const REVO_CVMAT& matU8(Slots<REVO_CVMAT>& v, revo_plane what, unsigned lvl) const {
+    auto& m = slot(v, lvl);
+    if (!m) {
+      const std::vector<uint8_t> d = readU8(what, lvl);
+      const Camera& c = cameraPyr->at((int)lvl);
+      m.reset(new REVO_CVMAT());
+      m->create((int)c.height, (int)c.width, CV_8UC1);
+      for (size_t y = 0; y < c.height; ++y) std::memcpy(m->data + y * (size_t)m->step, d.data() + y * c.width, c.width);
+    }
+    return *m;
+  }
+  mutable Slots<REVO_MATXF> m3d_;
+  mutable Slots<std::vector<REVO_VEC4F>> tab_;
+  mutable Slots<REVO_CVMAT> dt_, depth_, edges_, orig_, gray_;
+#endif
   ImgPyramidSettings mSettings;
   revo_pyr* pyr_ = nullptr;
   float T_w_f[16];
@@ -181,11 +289,14 @@ class Optimizer {  // optimizer.h:114-186
     int& badPtsEdges() { return bad_pts_edges; }
   };
   Optimizer(const OptimizerSettings& settings, const std::shared_ptr<CameraPyr>& cam) : mSettings(settings), cam_(cam) {}
+  explicit Optimizer(const OptimizerSettings& settings) : mSettings(settings) {}  // optimizer.h:166
+  void bind(const std::shared_ptr<CameraPyr>& cam) { cam_ = cam; }
   // float trackFrames(refFrame, currFrame, Matrix3f& R, Vector3f& T, int lvl, ResidualInfo&), optimizer.cpp:235-311
   template <class M3, class V3>
   float trackFrames(const std::shared_ptr<ImgPyramidRGBD>& refFrame, const std::shared_ptr<ImgPyramidRGBD>& currFrame, M3& R,
                     V3& T, int lvl, ResidualInfo& resInfo) {
     float err = 0.f;
+    if (!cam_) cam_ = refFrame->cameraPyr;
     check(revo_optimizer_track_level(cam_->ctx(), refFrame->handle(), currFrame->handle(), R.data(), T.data(), lvl, &resInfo, &err),
           "Optimizer::trackFrames");
     return err;
@@ -207,11 +318,17 @@ class TrackerNew {  // tracker.h:56-105
         mOptimizer(config.optimizerSettings, cam) {
     check(revo_ctx_set_tracker(cam->ctx(), &config.optimizerSettings, &config), "TrackerNew");
   }
+  // the reference's constructor (tracker.h:71): no camera pyramid -- the device context is the one of the first
+  // frame the tracker sees (every ImgPyramidRGBD carries its cameraPyr, imgpyramidrgbd.h:42)
+  TrackerNew(const TrackerSettings& config, const ImgPyramidSettings& pyrConfig)
+      : histogramLevel(config.histogram_level), mSettings(config), mPyrConfig(pyrConfig), cam_(nullptr),
+        mOptimizer(config.optimizerSettings, nullptr) {}
   // tracker.cpp:294-353
   template <class M3, class V3>
   TrackerStatus trackFrames(M3& R, V3& T, float& error, const std::shared_ptr<ImgPyramidRGBD>& refFrame,
                             const std::shared_ptr<ImgPyramidRGBD>& currFrame) {
     int status = TRACKER_STATE_UNKNOWN;
+    bind(refFrame->cameraPyr);
     check(revo_tracker_track_frames(cam_->ctx(), refFrame->handle(), currFrame->handle(), R.data(), T.data(), &error, &status,
                                     nullptr, lastEvals),
           "TrackerNew::trackFrames");
@@ -221,6 +338,7 @@ class TrackerNew {  // tracker.h:56-105
   template <class M4>
   TrackerStatus assessTrackingQuality(const M4& estimatedPose, const std::shared_ptr<ImgPyramidRGBD>& currFrame) {
     int status = TRACKER_STATE_OK;
+    bind(currFrame->cameraPyr);
     check(revo_tracker_assess_quality(cam_->ctx(), estimatedPose.data(), currFrame->handle(), &status, nullptr, nullptr),
           "assessTrackingQuality");
     return (TrackerStatus)status;
@@ -229,7 +347,29 @@ class TrackerNew {  // tracker.h:56-105
   // so the source pyramid and the level are passed instead
   template <class M4>
   void addOldPclAndPose(const std::shared_ptr<ImgPyramidRGBD>& src, int lvl, const M4& worldPose, double timeStamp) {
+    bind(src->cameraPyr);
     check(revo_tracker_add_old_pcl(cam_->ctx(), src->handle(), lvl, worldPose.data(), timeStamp), "addOldPclAndPose");
+  }
+  // the reference's signature, addOldPclAndPose(const Eigen::MatrixXf& pcl, const Eigen::Matrix4f& worldPose, double)
+  // (tracker.cpp:209-223; called with frame->return3DEdges(histogramLevel), system.cpp:173,259): a matrix that is the
+  // mirror of a pyramid's edge list is copied on the device, any other 4 x N matrix is uploaded
+  template <class MatX, class M4, class = decltype(std::declval<const MatX&>().cols())>
+  void addOldPclAndPose(const MatX& pcl, const M4& worldPose, double timeStamp) {
+    revo_pyr* src = nullptr;
+    int lvl = 0;
+    if (!cam_) fatal(REVO_ERR_INVALID_ARG, "addOldPclAndPose before the tracker has seen a frame");
+    if (MirrorRegistry::get().find(pcl.data(), &src, &lvl))
+      check(revo_tracker_add_old_pcl(cam_->ctx(), src, lvl, worldPose.data(), timeStamp), "addOldPclAndPose");
+    else
+      check(revo_tracker_add_old_pcl_host(cam_->ctx(), pcl.data(), (size_t)pcl.cols(), worldPose.data(), timeStamp), "addOldPclAndPose");
+  }
+  // binds the tracker to the device context of the frames it is used with
+  void bind(const std::shared_ptr<CameraPyr>& cam) {
+    if (cam_ == cam) return;
+    if (cam_) fatal(REVO_ERR_INVALID_ARG, "TrackerNew used with frames of two camera pyramids");
+    cam_ = cam;
+    mOptimizer.bind(cam);
+    check(revo_ctx_set_tracker(cam->ctx(), &mSettings.optimizerSettings, &mSettings), "TrackerNew");
   }
   void clearUpPastLists() { check(revo_tracker_clear_past(cam_->ctx()), "clearUpPastLists"); }  // tracker.cpp:248-257
   int32_t lastEvals[REVO_MAX_LEVELS] = {0, 0, 0, 0, 0, 0};

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "revo_dev.h"
+#include "revo_mat4.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local std::string g_err;
@@ -77,6 +78,7 @@ struct FrameSet {
 
 struct Past {  // one entry of mPastPcl / mPastWorldPoses / mPastTimeStamps (tracker.h:92-95)
   float4* d_pts; int* d_n; int n; float T_w[16]; double ts;
+  size_t cap;  // points the buffer holds
 };
 
 struct revo_ctx {
@@ -218,7 +220,9 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
     const char* e = getenv("REVO_TRACK_KSPEC");
     const size_t n = e ? strlen(e) : 0;
     for (int i = 0; i < REVO_L; ++i) {
-      int k = TRACK_KMAX;
+      // default: the two finest levels evaluate one retry next to the candidate (their points are what a pass costs),
+      // the coarse ones three (profiles/r02_single_stream_sweep.txt)
+      int k = i < 2 ? 2 : TRACK_KMAX;
       if (n == 1) k = e[0] - '0'; else if (n > 1) k = e[std::min<size_t>(i, n - 1)] - '0';
       t->kspec[i] = std::max(1, std::min(TRACK_KMAX, k));
     }
@@ -323,9 +327,9 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
   if (with_staging) {
     HIPCHECK(hipHostMalloc((void**)&fs->h_bgr, (size_t)g.lv[0].npix * 3 * B));
     HIPCHECK(hipHostMalloc((void**)&fs->h_depth, (size_t)g.lv[0].npix * 4 * B));
-    HIPCHECK(hipEventCreateWithFlags(&fs->ev_ready, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&fs->ev_free, hipEventDisableTiming));
   }
+  HIPCHECK(hipEventCreateWithFlags(&fs->ev_ready, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&fs->ev_free, hipEventDisableTiming));
   // counts start at zero so an accessor on a not-yet-built pyramid is well defined
   hipMemsetAsync(fs->p.npts, 0, sizeof(int) * REVO_L * B, c->stream);
   HIPCHECK(hipStreamSynchronize(c->stream));
@@ -453,7 +457,9 @@ extern "C" int revo_ctx_camera(const revo_ctx* c, int lvl, float out6[6]) {
 // ----------------------------------------------------------------- pyramids --
 // Order the consumer stream after the (asynchronous) build of a single-frame pyramid.
 static int wait_ready(revo_ctx* c, const revo_pyr* p) {
-  if (p->owns_fs && p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
+  // single-frame pyramids: built on the build stream; batch views: built on the batch's / the caller's stream
+  // (revo_batch_build records the event) -- either way the consumer stream is ordered behind the build
+  if (p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
   return REVO_OK;
 }
 
@@ -750,37 +756,6 @@ extern "C" int revo_tracker_track_frames(revo_ctx* c, const revo_pyr* ref, const
   return REVO_OK;
 }
 
-// ---- 4x4 helpers (column-major), Eigen Matrix4f::inverse() semantics (tracker.cpp:142)
-static void mat4_inverse(const float* m, float* inv) {
-  float o[16];
-  o[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
-  o[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
-  o[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
-  o[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
-  o[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
-  o[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
-  o[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
-  o[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
-  o[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
-  o[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
-  o[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
-  o[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
-  o[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
-  o[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
-  o[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
-  o[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-  const float det = m[0] * o[0] + m[1] * o[4] + m[2] * o[8] + m[3] * o[12];
-  const float idet = 1.0f / det;
-  for (int i = 0; i < 16; ++i) inv[i] = o[i] * idet;
-}
-static void mat4_mul(const float* A, const float* B, float* out) {
-  float o[16];
-  for (int c = 0; c < 4; ++c)
-    for (int r = 0; r < 4; ++r)
-      o[c * 4 + r] = A[0 * 4 + r] * B[c * 4 + 0] + A[1 * 4 + r] * B[c * 4 + 1] + A[2 * 4 + r] * B[c * 4 + 2] + A[3 * 4 + r] * B[c * 4 + 3];
-  memcpy(out, o, sizeof(o));
-}
-
 extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* status,
                                            int32_t hist4[4], int32_t overlaps4[4]) {
   if (!c || !T_w_curr || !curr) return fail(REVO_ERR_INVALID_ARG, "null argument");
@@ -825,28 +800,57 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
   return REVO_OK;
 }
 
+// a past-cloud buffer for at least `need` points: recycled if one is large enough (no hipMalloc per frame in
+// the steady state), sized for what is stored -- the histogram level's cloud, not level 0's
+static int past_take(revo_ctx* c, size_t need, Past* out) {
+  for (size_t k = 0; k < c->past_pool.size(); ++k)
+    if (c->past_pool[k].cap >= need) { *out = c->past_pool[k]; c->past_pool.erase(c->past_pool.begin() + k); return REVO_OK; }
+  Past p{};
+  p.cap = std::max<size_t>(need, 1024);
+  HIPCHECK(hipMalloc((void**)&p.d_pts, sizeof(float4) * p.cap));
+  hipError_t e = hipMalloc((void**)&p.d_n, sizeof(int));
+  if (e != hipSuccess) { (void)hipFree(p.d_pts); return fail(REVO_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  *out = p;
+  return REVO_OK;
+}
+
 extern "C" int revo_tracker_add_old_pcl(revo_ctx* c, const revo_pyr* src, int lvl, const float T_w[16], double ts) {
   if (!c || !src || !T_w) return fail(REVO_ERR_INVALID_ARG, "null argument");
   if (lvl < 0 || lvl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "level out of range");
   HIPCHECK(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
   // the reference copies the Eigen matrix (tracker.cpp:219); the copy stays in HBM, in a
-  // recycled buffer sized for the level (no hipMalloc per frame)
+  // recycled buffer sized for the level
   { int rc = wait_ready(c, src); if (rc) return rc; }
   Past p{};
   const size_t f = (size_t)src->frame;
-  if (!c->past_pool.empty()) { p = c->past_pool.back(); c->past_pool.pop_back(); }
-  else {
-    size_t maxpix = 0;
-    for (int l = 0; l < c->geom.n_levels; ++l) maxpix = std::max(maxpix, (size_t)c->geom.lv[l].npix);
-    HIPCHECK(hipMalloc((void**)&p.d_pts, sizeof(float4) * maxpix));
-    HIPCHECK(hipMalloc((void**)&p.d_n, sizeof(int)));
-  }
+  { int rc = past_take(c, (size_t)c->geom.lv[lvl].npix, &p); if (rc) return rc; }
   // the count stays on the device: one kernel copies the n valid points and n (stream ordered)
   launch_copy_cloud(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, p.d_n, src->fs->p.npts + f * REVO_L + lvl,
                     c->stream);
   HIPCHECK(hipGetLastError());
   p.n = -1;
+  memcpy(p.T_w, T_w, sizeof(float) * 16);
+  p.ts = ts;
+  c->past.push_back(p);
+  return REVO_OK;
+}
+
+// addOldPclAndPose(const Eigen::MatrixXf& pcl, const Eigen::Matrix4f& worldPose, double timeStamp), tracker.cpp:209-223,
+// with the cloud in host memory (4 x n column-major = n packed float4)
+extern "C" int revo_tracker_add_old_pcl_host(revo_ctx* c, const float* pcl, size_t n, const float T_w[16], double ts) {
+  if (!c || !T_w || (!pcl && n)) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (n > (size_t)c->geom.lv[0].npix) return fail(REVO_ERR_CAPACITY, "more points than pixels");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  Past p{};
+  { int rc = past_take(c, n, &p); if (rc) return rc; }
+  const int ni = (int)n;
+  // pageable source: the runtime has read it when the call returns (the caller's matrix may die right after)
+  if (n) HIPCHECK(hipMemcpyAsync(p.d_pts, pcl, sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(p.d_n, &ni, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  p.n = ni;
   memcpy(p.T_w, T_w, sizeof(float) * 16);
   p.ts = ts;
   c->past.push_back(p);
@@ -921,6 +925,8 @@ extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float
   enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s);
   launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
   HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
+  b->fs->has_ready = true;
   for (auto& v : b->views) v.table_built = false;
   return REVO_OK;
 }
@@ -965,6 +971,8 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s);
   launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);
   HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
+  b->fs->has_ready = true;
   for (auto& v : b->views) v.table_built = false;
   return REVO_OK;
 }

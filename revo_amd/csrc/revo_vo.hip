@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "../../include/revo_hip.h"
+#include "revo_mat4.h"
 
 extern "C" void revo_ctx_retain_(revo_ctx*);
 extern "C" void revo_ctx_release_(revo_ctx*);
@@ -16,38 +17,8 @@ struct M4 {  // column-major 4x4, Eigen::Matrix4f storage
   float m[16];
   static M4 identity() { M4 o; memset(o.m, 0, sizeof(o.m)); o.m[0] = o.m[5] = o.m[10] = o.m[15] = 1.f; return o; }
 };
-M4 mul(const M4& A, const M4& B) {
-  M4 o;
-  for (int c = 0; c < 4; ++c)
-    for (int r = 0; r < 4; ++r)
-      o.m[c * 4 + r] = A.m[r] * B.m[c * 4] + A.m[4 + r] * B.m[c * 4 + 1] + A.m[8 + r] * B.m[c * 4 + 2] + A.m[12 + r] * B.m[c * 4 + 3];
-  return o;
-}
-M4 inverse(const M4& A) {  // Eigen Matrix4f::inverse(): general cofactor inverse, float
-  const float* m = A.m;
-  float o[16];
-  o[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
-  o[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
-  o[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
-  o[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
-  o[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
-  o[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
-  o[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
-  o[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
-  o[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
-  o[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
-  o[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
-  o[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
-  o[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
-  o[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
-  o[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
-  o[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-  const float det = m[0] * o[0] + m[1] * o[4] + m[2] * o[8] + m[3] * o[12];
-  const float idet = 1.0f / det;
-  M4 r;
-  for (int i = 0; i < 16; ++i) r.m[i] = o[i] * idet;
-  return r;
-}
+M4 mul(const M4& A, const M4& B) { M4 o; mat4_mul(A.m, B.m, o.m); return o; }
+M4 inverse(const M4& A) { M4 o; mat4_inverse(A.m, o.m); return o; }  // Eigen Matrix4f::inverse()
 M4 from_RT(const float* R, const float* T) {  // transformFromRT
   M4 o = M4::identity();
   for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) o.m[c * 4 + r] = R[c * 3 + r];

@@ -21,8 +21,8 @@ def read_associate(path, skip_first_n_frames=0, read_n_images=None):
         if len(p) < 4:
             raise ValueError("bad associate line: %r" % line)
         out.append((float(p[0]), p[1], float(p[2]), p[3]))
-        if read_n_images is not None and len(out) >= read_n_images:
-            break
+        if read_n_images is not None and len(out) > read_n_images:  # `if (nFrames > READ_N_IMAGES) break;` after the
+            break                                                      # push: N + 1 frames (iowrapperRGBD.cpp:291)
     return out
 
 

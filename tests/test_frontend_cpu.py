@@ -53,9 +53,13 @@ def test_yaml_readers(tmp_path):
     assert filt == 1 and sysd["do_output_poses"] == 1
     # defaults for missing keys follow cv::read(..., default) (camerapyr.h:40-64)
     e = tmp_path / "empty.yaml"
-    e.write_text("%YAML:1.0\nCamera.width: 320\nCamera.height: 240\n")
-    s2, _ = config.load_dataset_yaml(str(e))
+    e.write_text("%YAML:1.0\nwidth: 320\nheight: 240\nCamera.width: 1280\n")
+    s2, io2 = config.load_dataset_yaml(str(e))
+    # camerapyr.h:51-61: the pyramid reads "width"/"height"; Camera.width only sizes the IO wrapper's images
+    assert (s2.width, s2.height) == (320, 240) and io2["img_width"] == 1280
     assert s2.fx == (320 + 240) / 2 and s2.fy == s2.fx and s2.cx == 160 and s2.pyr_min_lvl == 2
+    # the reference's defaults for absent keys (iowrapperRGBD.h:119,126)
+    assert io2["depth_scale_factor"] == 1000.0 and io2["use_depth_timestamp"] == 1
 
 
 def test_tum_layout_roundtrip(tmp_path):
@@ -65,7 +69,8 @@ def test_tum_layout_roundtrip(tmp_path):
     tum.write_synthetic_dataset(folder, seq)
     rows = tum.read_associate(folder + "/associate.txt")
     assert len(rows) == 4 and rows[0][1].startswith("rgb/") and rows[0][3].startswith("depth/")
-    assert len(tum.read_associate(folder + "/associate.txt", skip_first_n_frames=1, read_n_images=2)) == 2
+    # READ_N_IMAGES = n reads n + 1 frames, like the reference's `if (nFrames > READ_N_IMAGES) break;` (iowrapperRGBD.cpp:291)
+    assert len(tum.read_associate(folder + "/associate.txt", skip_first_n_frames=1, read_n_images=1)) == 2
     got = list(tum.frames(folder))
     for (bgr, raw, ts), (bgr0, depth0, ts0, T) in zip(got, seq):
         assert np.array_equal(bgr, bgr0) and abs(ts - ts0) < 1e-6 and raw.dtype == np.uint16

@@ -71,7 +71,7 @@ def test_run_tum_cli_on_a_synthetic_tum_dataset(tmp_path, monkeypatch):
     folder = tmp_path / "data" / "rgbd_dataset_synth"
     tum.write_synthetic_dataset(str(folder), seq)
     (tmp_path / "dataset.yaml").write_text(
-        "%%YAML:1.0\nCamera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.width: 320\nCamera.height: 240\n"
+        "%%YAML:1.0\nCamera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.width: 320\nCamera.height: 240\nwidth: 320\nheight: 240\n"
         "MainFolder: \"%s/\"\nDatasets: \"rgbd_dataset_synth\"\nASSOCIATE: \"associate.txt\"\n"
         "PYR_MIN_LVL: 2\nPYR_MAX_LVL: 0\nDEPTH_SCALE_FACTOR: 5000.0\n"
         % (float(s.fx), float(s.fy), float(s.cx), float(s.cy), str(tmp_path / "data")))

@@ -171,3 +171,12 @@ assert parallel.gather_records(local, 1) is local  # no group: a single rank's r
     env = parallel.rendezvous_env(0, 1)
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
+
+
+def test_cpp_adapters_compile_against_reference_shaped_types():
+    """tests/cpp/adapter_refshape.cpp static_asserts the reference's signatures (imgpyramidrgbd.h:45-117,
+    tracker.h:69-80) on the adapters, against Eigen / cv shaped stand-ins; both hosts must compile."""
+    for src in ("adapter_refshape.cpp", "adapter_track.cpp"):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "cpp", src)],
+                           capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
