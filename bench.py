@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--render-procs", type=int, default=0, help="0 = auto")
     ap.add_argument("--no-overlap", action="store_true", help="single batch, single stream (no build/track overlap)")
     ap.add_argument("--single-stream-frames", type=int, default=60, help="0 = skip the sequential-VO side measurement")
+    ap.add_argument("--skip-host-buffers", action="store_true", help="skip the host-buffer (H2D-inclusive) side measurement")
     ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the world-size-1 RCCL group")
     a = ap.parse_args()
 
@@ -283,7 +284,7 @@ def main():
     # HBM traffic of k_track per launch from the PMC passes recorded under profiles/ (same workload;
     # counters cannot be collected inside this process)
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if os.path.exists(pmc_file) and a.pairs == 32 and a.width == 640 and a.levels == 4:
         try:
             traffic = float(json.load(open(pmc_file))["k_track"]["hbm_bytes_per_launch"])
@@ -341,7 +342,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+            "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of the default double-buffered command, this round's kernels)" if traffic else None,
             "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track, "kernel_ms_alone": ms_track_alone,
             "frac_alone": b_trk / (ms_track_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "timing": "HIP events on the tracker's stream around each of the %d timed launches" % max(1, len(track_events)),
@@ -367,7 +368,7 @@ def main():
     # ---- the same step fed from HOST memory (revo_track_pairs_submit / _wait): page-locked frames as a decoder
     # thread would leave them, H2D on its own stream overlapped with the kernels of the previous job.  Reported
     # next to `value` (which has its inputs resident in HBM); PCIe-bound.
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.skip_host_buffers:
         from collections import deque
         hostb = {}
         for tag, scale in (("u16", 5000.0), ("f32", None)):

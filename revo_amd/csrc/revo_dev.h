@@ -124,8 +124,10 @@ void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride
 // epoch_io: per-mailbox epoch counter kept by the owner of d_mail (zero it together with the mailbox)
 void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
                   int n_pairs, unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
+// seq_ptr (pinned host memory, may be null): receives seq_val after the result record has been written
 void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
-                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
+                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,
+                      hipStream_t s);
 void launch_solve6(const float* d_Ab /*n x 43: A 36, b 6, lambda*/, int n, float* d_x /*n x 6*/, hipStream_t s);
 int track_blocks_per_cu();  // occupancy query of k_track (advisory)
 void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
@@ -134,5 +136,6 @@ void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstri
 struct VoteArgs { float RT[3][12]; const float4* pts[3]; const int* n[3]; };
 void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds, const VoteArgs& va,
                  int* d_marks /*npix, all-zero in/out*/, int* d_hist8 /*all-zero in/out*/, unsigned* d_done /*zero in/out*/,
-                 int* h_out8 /*pinned host: hist[4], overlaps[4]*/, int use_orig_edges, hipStream_t s);
+                 int* h_out8 /*pinned host: hist[4], overlaps[4], then the sequence word*/, unsigned seq_val, int use_orig_edges,
+                 hipStream_t s);
 void launch_copy_cloud(float4* dst, const float4* src, int* dst_n, const int* src_n, hipStream_t s);

@@ -98,8 +98,10 @@ struct revo_ctx {
   // the kernel reads the descriptor from its argument segment and writes the result straight into
   // pinned host memory: one launch + one sync per trackFrames, no copies on the stream
   PairDesc* h_desc;
-  revo_pair_result* h_res;
+  revo_pair_result* h_res;      // [2]: two single-pair launches may be in flight (the VO driver's look-ahead)
   EvalOut* h_eval;
+  unsigned* h_seq;              // [3] pinned: sequence words the kernels write after their results (2 tracker slots, vote)
+  unsigned seq_next = 1;
   unsigned long long* d_mail;   // cluster mailbox of the single-pair path
   unsigned mail_epoch = 0;      // next free epoch window of d_mail (launch_track_one)
   int num_cus, blocks_per_cu;
@@ -382,7 +384,9 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHECK(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
-  HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result)));
+  HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result) * 2));
+  HIPCHECK(hipHostMalloc((void**)&c->h_seq, sizeof(unsigned) * 4));
+  memset(c->h_seq, 0, sizeof(unsigned) * 4);
   HIPCHECK(hipHostMalloc((void**)&c->h_eval, sizeof(EvalOut)));
   hipDeviceProp_t prop;
   HIPCHECK(hipGetDeviceProperties(&prop, device));
@@ -399,7 +403,8 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipMemset(c->d_marks, 0, sizeof(int) * maxpix));
   HIPCHECK(hipMemset(c->d_hist8, 0, sizeof(int) * 8));
   HIPCHECK(hipMemset(c->d_vote_done, 0, sizeof(unsigned)));
-  HIPCHECK(hipHostMalloc((void**)&c->h_hist8, sizeof(int) * 8));
+  HIPCHECK(hipHostMalloc((void**)&c->h_hist8, sizeof(int) * 16));  // hist[4], overlaps[4], sequence word
+  memset(c->h_hist8, 0, sizeof(int) * 16);
   guard.c = nullptr;
   *out = c;
   return REVO_OK;
@@ -416,7 +421,7 @@ static void ctx_free(revo_ctx* c) {
   for (auto& p : c->past_pool) { hipFree(p.d_pts); hipFree(p.d_n); }
   if (c->build_stream) hipStreamDestroy(c->build_stream);
   for (FrameSet* fs : c->pool) frameset_destroy(fs);
-  hipHostFree(c->h_desc); hipHostFree(c->h_res); hipHostFree(c->h_eval); hipFree(c->d_mail);
+  hipHostFree(c->h_desc); hipHostFree(c->h_res); hipHostFree(c->h_eval); hipHostFree(c->h_seq); hipFree(c->d_mail);
   hipFree(c->d_marks); hipFree(c->d_hist8); hipHostFree(c->h_hist8); hipFree(c->d_vote_done);
   hipFree(c->d_pcl);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -654,18 +659,78 @@ static int check_pair(const revo_ctx* c, const revo_pyr* ref, const revo_pyr* cu
   return REVO_OK;
 }
 
-static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
-                      const TrackParams& tp) {
+// Waits for a sequence word a kernel writes (system scope) after its results in pinned host memory: a short spin
+// (the kernel is usually about to finish: a stream synchronise costs a sleep / wake-up of the calling thread),
+// then the stream.
+static int wait_seq(revo_ctx* c, volatile unsigned* word, unsigned want) {
+  for (int spin = 0; spin < 200000; ++spin) {
+    if (*word == want) { std::atomic_thread_fence(std::memory_order_acquire); return REVO_OK; }
+    __builtin_ia32_pause();
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (*word != want) return fail(REVO_ERR_HIP, "a kernel finished without publishing its result");
+  return REVO_OK;
+}
+
+// One single-pair tracker launch into result slot `slot` (0 / 1); *seq_out identifies it for track_wait.
+static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
+                        const TrackParams& tp, int slot, unsigned* seq_out) {
   fill_desc(c->h_desc, ref, curr, R, T);
   { int rc = wait_ready(c, ref); if (rc) return rc; rc = wait_ready(c, curr); if (rc) return rc; }
   TrackParams tp1 = tp;
   tp1.redundant_n = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
+  const unsigned seq = c->seq_next++;
+  if (c->seq_next == 0) c->seq_next = 1;
   const int rc = chained_track_launch(c->device, c->stream, [&] {
-    launch_track_one(*c->h_desc, tp1, c->h_res, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->stream);
+    launch_track_one(*c->h_desc, tp1, c->h_res + slot, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->h_seq + slot, seq,
+                     c->stream);
   });
   if (rc) return rc;
-  HIPCHECK(hipStreamSynchronize(c->stream));
+  *seq_out = seq;
   return REVO_OK;
+}
+static int track_wait(revo_ctx* c, int slot, unsigned seq) { return wait_seq(c, c->h_seq + slot, seq); }
+
+static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
+                      const TrackParams& tp) {
+  unsigned seq = 0;
+  int rc = track_launch(c, ref, curr, R, T, tp, 0, &seq);
+  if (rc) return rc;
+  if (tp.eval_only) {  // the EvalOut record is written by many lanes: wait for the stream, not for a word
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return REVO_OK;
+  }
+  return track_wait(c, 0, seq);
+}
+
+static int decode_track(const revo_pair_result& r, float R[9], float T[3], float* err, int* status, revo_residual_info* info,
+                        int32_t* iters) {
+  if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
+  if (r.flags & 8) return fail(REVO_ERR_HIP, "tracker: the workgroups of the pair could not exchange partial sums in time (device shared?)");
+  memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
+  if (err) *err = r.err;
+  if (status) *status = r.status;
+  if (info) { info->good_pts_edges = r.good; info->bad_pts_edges = r.bad; info->sum_error_unweighted = 0.f; info->sum_error_weighted = 0.f; }
+  if (iters) memcpy(iters, r.evals, sizeof(int32_t) * REVO_L);
+  return REVO_OK;
+}
+
+// ---- split calls for the VO driver's look-ahead (revo_vo.hip); not part of the public ABI
+extern "C" int revo_track_launch_(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float R[9], const float T[3], int slot,
+                                  unsigned* seq_out) {
+  int rc = check_pair(c, ref, curr);
+  if (rc) return rc;
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  TrackParams tp = c->tp;
+  tp.eval_only = 0;
+  return track_launch(c, ref, curr, R, T, tp, slot & 1, seq_out);
+}
+extern "C" int revo_track_wait_(revo_ctx* c, int slot, unsigned seq, float R[9], float T[3], float* err, int* status) {
+  if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
+  int rc = track_wait(c, slot & 1, seq);
+  if (rc) return rc;
+  return decode_track(c->h_res[slot & 1], R, T, err, status, nullptr, nullptr);
 }
 
 extern "C" int revo_optimizer_track_level(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, float R[9], float T[3],
@@ -680,13 +745,7 @@ extern "C" int revo_optimizer_track_level(revo_ctx* c, const revo_pyr* ref, cons
   tp.lvl_begin = tp.lvl_end = lvl; tp.check_init = 0; tp.eval_only = 0;
   rc = run_single(c, ref, curr, R, T, tp);
   if (rc) return rc;
-  const revo_pair_result& r = *c->h_res;
-  if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
-  if (r.flags & 8) return fail(REVO_ERR_HIP, "tracker: the workgroups of the pair could not exchange partial sums in time (device shared?)");
-  memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
-  if (err) *err = r.err;
-  if (info) { info->good_pts_edges = r.good; info->bad_pts_edges = r.bad; info->sum_error_unweighted = 0.f; info->sum_error_weighted = 0.f; }
-  return REVO_OK;
+  return decode_track(c->h_res[0], R, T, err, nullptr, info, nullptr);
 }
 
 extern "C" int revo_optimizer_eval(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float R[9],
@@ -745,29 +804,15 @@ extern "C" int revo_tracker_track_frames(revo_ctx* c, const revo_pyr* ref, const
   tp.eval_only = 0;
   rc = run_single(c, ref, curr, R, T, tp);
   if (rc) return rc;
-  const revo_pair_result& r = *c->h_res;
-  if (r.flags & 2) return fail(REVO_ERR_NOT_ORTHOGONAL, "R is not orthogonal (Sophus::SO3 precondition)");
-  if (r.flags & 8) return fail(REVO_ERR_HIP, "tracker: the workgroups of the pair could not exchange partial sums in time (device shared?)");
-  memcpy(R, r.R, sizeof(float) * 9); memcpy(T, r.T, sizeof(float) * 3);
-  if (err) *err = r.err;
-  if (status) *status = r.status;
-  if (info) { info->good_pts_edges = r.good; info->bad_pts_edges = r.bad; info->sum_error_unweighted = 0.f; info->sum_error_weighted = 0.f; }
-  if (iters) memcpy(iters, r.evals, sizeof(int32_t) * REVO_L);
-  return REVO_OK;
+  return decode_track(c->h_res[0], R, T, err, status, info, iters);
 }
 
-extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* status,
-                                           int32_t hist4[4], int32_t overlaps4[4]) {
-  if (!c || !T_w_curr || !curr) return fail(REVO_ERR_INVALID_ARG, "null argument");
-  if (curr->ctx != c) return fail(REVO_ERR_INVALID_ARG, "pyramid belongs to another context");
-  if (hist4) memset(hist4, 0, sizeof(int32_t) * 4);
-  if (overlaps4) memset(overlaps4, 0, sizeof(int32_t) * 4);
-  if (status) *status = REVO_TRACKER_STATE_OK;
-  std::lock_guard<std::mutex> lk(c->mu);
-  if (c->past.empty() || !c->ts.check_tracking_results) return REVO_OK;  // tracker.cpp:121
+// assessTrackingQuality (tracker.cpp:118-201) in two halves: enqueue the vote kernels / read the counts
+static int assess_launch(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out) {
+  *nframes_out = -1;  // -1: nothing to vote on (tracker.cpp:121)
+  if (c->past.empty() || !c->ts.check_tracking_results) return REVO_OK;
   const int hl = c->ts.histogram_level;
   if (hl < 0 || hl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "histogram_level outside the pyramid");
-  HIPCHECK(hipSetDevice(c->device));
   { int rc = wait_ready(c, curr); if (rc) return rc; }
   float inv[16];
   mat4_inverse(T_w_curr, inv);
@@ -784,10 +829,19 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
     ++nframes;
   }
   const int use_orig = c->geom.lv[hl].has_orig;  // returnOrigEdges(lvl), imgpyramidrgbd.h:67-75 (elsewhere the clone equals edgesPyr)
-  launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, va, c->d_marks, c->d_hist8, c->d_vote_done, c->h_hist8,
+  const unsigned seq = c->seq_next++;
+  if (c->seq_next == 0) c->seq_next = 1;
+  launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, va, c->d_marks, c->d_hist8, c->d_vote_done, c->h_hist8, seq,
               use_orig, c->stream);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipStreamSynchronize(c->stream));
+  *nframes_out = nframes;
+  *seq_out = seq;
+  return REVO_OK;
+}
+static int assess_wait(revo_ctx* c, int nframes, unsigned seq, int* status, int32_t hist4[4], int32_t overlaps4[4]) {
+  if (status) *status = REVO_TRACKER_STATE_OK;
+  if (nframes < 0) return REVO_OK;
+  { int rc = wait_seq(c, (volatile unsigned*)(c->h_hist8 + 8), seq); if (rc) return rc; }
   const int* hist = c->h_hist8;
   const int* ov = c->h_hist8 + 4;
   const float wts[4] = {0.f, 1.f, 1.25f, 1.5f};  // tracker.cpp:231-234
@@ -798,6 +852,33 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
   if (overlaps4) memcpy(overlaps4, ov, sizeof(int32_t) * 4);
   if (status) *status = (overlapMeasure >= ov[0] || hsize < 4) ? REVO_TRACKER_STATE_OK : REVO_TRACKER_STATE_NEW_KF;  // tracker.cpp:184
   return REVO_OK;
+}
+
+extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* status,
+                                           int32_t hist4[4], int32_t overlaps4[4]) {
+  if (!c || !T_w_curr || !curr) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  if (curr->ctx != c) return fail(REVO_ERR_INVALID_ARG, "pyramid belongs to another context");
+  if (hist4) memset(hist4, 0, sizeof(int32_t) * 4);
+  if (overlaps4) memset(overlaps4, 0, sizeof(int32_t) * 4);
+  if (status) *status = REVO_TRACKER_STATE_OK;
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  int nframes = -1;
+  unsigned seq = 0;
+  int rc = assess_launch(c, T_w_curr, curr, &nframes, &seq);
+  if (rc) return rc;
+  return assess_wait(c, nframes, seq, status, hist4, overlaps4);
+}
+// split form for the VO driver's look-ahead (revo_vo.hip); not part of the public ABI
+extern "C" int revo_assess_launch_(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out) {
+  if (!c || !T_w_curr || !curr || curr->ctx != c) return fail(REVO_ERR_INVALID_ARG, "bad argument");
+  HIPCHECK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  return assess_launch(c, T_w_curr, curr, nframes_out, seq_out);
+}
+extern "C" int revo_assess_wait_(revo_ctx* c, int nframes, unsigned seq, int* status) {
+  if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
+  return assess_wait(c, nframes, seq, status, nullptr, nullptr);
 }
 
 // a past-cloud buffer for at least `need` points: recycled if one is large enough (no hipMalloc per frame in

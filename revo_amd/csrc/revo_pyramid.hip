@@ -12,6 +12,7 @@
 // Exactness: every integer stage is bit-exact by construction; float stages
 // keep the reference's operation order and are compiled with -ffp-contract=off.
 #include "revo_dev.h"
+#include <type_traits>
 
 namespace {
 
@@ -183,10 +184,15 @@ __device__ __forceinline__ HRow hrow(uint32_t prev, uint32_t m0, uint32_t m1, ui
   return r;
 }
 
-// Sobel of the row between a (above) and c (below), b the row itself: |grad|^2 of columns -1..8 into m[10],
-// (dx | dy << 16) of columns 0..7 into dxy[8]; cm[]: column masks (0 outside the image)
-__device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm, bool valid, int* m,
-                                        uint32_t* dxy) {
+// A row of magnitudes / gradients lives in a VECTOR value, not an array: element access with a constant index is an
+// SSA extract, so "neg ? A[i+1] : A[i-1]" stays a select of two values.  With arrays the optimiser rewrote it as ONE
+// load through a selected POINTER, which pinned the arrays to scratch memory (420 MB of HBM traffic per launch).
+typedef int mrow_t __attribute__((ext_vector_type(16)));        // |grad|^2 of columns -1..8 (10 used)
+typedef uint32_t drow_t __attribute__((ext_vector_type(8)));    // (dx | dy << 16) of columns 0..7
+
+// Sobel of the row between a (above) and c (below), b the row itself; cm[]: column masks (0 outside the image)
+__device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm, bool valid, mrow_t& m,
+                                        drow_t& dxy) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const s2v dx = (a.d[k] + c.d[k]) + (b.d[k] + b.d[k]);
@@ -211,7 +217,7 @@ __device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow
 
 // NMS of one row (cv::Canny): 8 candidate bits and 8 strong bits.  A, B, C: |grad|^2 of the rows above, at and
 // below; dxy: the row's own gradients
-__device__ __forceinline__ void nms_row(const int* A, const int* B, const int* C, const uint32_t* dxyB, int low, int high,
+__device__ __forceinline__ void nms_row(const mrow_t& A, const mrow_t& B, const mrow_t& C, const drow_t& dxyB, int low, int high,
                                         uint32_t* cand, uint32_t* strong) {
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
   uint32_t cb = 0, sb = 0;
@@ -277,24 +283,19 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     if (!has_next) next = (m1 >> 24) * 0x01010101u;
     return hrow(prev, m0, m1, next);
   };
-  // Three gray rows (H) and three magnitude rows (M) in flight; the loop is fully unrolled and the slots are
-  // addressed with compile-time indices, so nothing moves and nothing is indexed dynamically.
-  HRow H[3];
-  int M[3][10];
-  uint32_t D[3][8];
-  H[0] = load_hrow(y0 - 2); H[1] = load_hrow(y0 - 1); H[2] = load_hrow(y0);
-  mag_row(H[0], H[1], H[2], cm, active && y0 - 1 >= 0, M[0], D[0]);                  // magnitude row y0 - 1
-  H[0] = load_hrow(y0 + 1);
-  mag_row(H[1], H[2], H[0], cm, active, M[1], D[1]);                                 // magnitude row y0
+  // Three gray rows (H*) and three magnitude rows (M*, D*) in flight, as separately named arrays picked with
+  // compile-time indices: nothing moves, nothing is indexed dynamically (2-D arrays indexed through a run-time-looking
+  // expression were left in scratch memory by the compiler: 420 MB of HBM traffic per launch instead of 33).
+  HRow H0, H1, H2;
+  mrow_t M0 = 0, M1 = 0, M2 = 0;
+  drow_t D0 = 0, D1 = 0, D2 = 0;
+  H0 = load_hrow(y0 - 2); H1 = load_hrow(y0 - 1); H2 = load_hrow(y0);
+  mag_row(H0, H1, H2, cm, active && y0 - 1 >= 0, M0, D0);                  // magnitude row y0 - 1
+  H0 = load_hrow(y0 + 1);
+  mag_row(H1, H2, H0, cm, active, M1, D1);                                 // magnitude row y0
   uint2* out = pl.cs[l] + ((size_t)f * h + y0) * lv.wpr + (xg >> 2);
   const int sh = 8 * (threadIdx.x & 3);
-#pragma unroll
-  for (int i = 0; i < NMS_R; ++i) {
-    // gray rows y0+i, y0+i+1 are in H[(i+2)%3], H[i%3]; row y0+i+2 replaces the oldest, H[(i+1)%3]
-    H[(i + 1) % 3] = load_hrow(y0 + i + 2);
-    mag_row(H[(i + 2) % 3], H[i % 3], H[(i + 1) % 3], cm, active && y0 + i + 1 < h, M[(i + 2) % 3], D[(i + 2) % 3]);  // row y0+i+1
-    uint32_t cb, sb;
-    nms_row(M[i % 3], M[(i + 1) % 3], M[(i + 2) % 3], D[(i + 1) % 3], g.canny_low, g.canny_high, &cb, &sb);
+  auto emit = [&](int i, uint32_t cb, uint32_t sb) {
     // a quad's four bytes -> one word (DPP quad_perm: no LDS)
     uint32_t cw = cb << sh, sw = sb << sh;
     cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
@@ -302,7 +303,25 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
     cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
     sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0x4E, 0xf, 0xf, true);
     if ((threadIdx.x & 3) == 0 && y0 + i < h) out[(size_t)i * lv.wpr] = make_uint2(cw, sw);
+  };
+  // step i: gray rows y0+i, y0+i+1 sit in (Ha, Hb); row y0+i+2 replaces the oldest (Hc); magnitude rows y0+i-1, y0+i in
+  // (Ma, Mb), row y0+i+1 goes to Mc
+#define NMS_STEP(i, Ha, Hb, Hc, Ma, Mb, Mc, Db, Dc)                                   \
+  {                                                                                   \
+    Hc = load_hrow(y0 + (i) + 2);                                                     \
+    mag_row(Ha, Hb, Hc, cm, active && y0 + (i) + 1 < h, Mc, Dc);                      \
+    uint32_t cb, sb;                                                                  \
+    nms_row(Ma, Mb, Mc, Db, g.canny_low, g.canny_high, &cb, &sb);                     \
+    emit((i), cb, sb);                                                                \
   }
+  NMS_STEP(0, H2, H0, H1, M0, M1, M2, D1, D2)
+  NMS_STEP(1, H0, H1, H2, M1, M2, M0, D2, D0)
+  NMS_STEP(2, H1, H2, H0, M2, M0, M1, D0, D1)
+  NMS_STEP(3, H2, H0, H1, M0, M1, M2, D1, D2)
+  NMS_STEP(4, H0, H1, H2, M1, M2, M0, D2, D0)
+  NMS_STEP(5, H1, H2, H0, M2, M0, M1, D0, D1)
+#undef NMS_STEP
+  static_assert(NMS_R == 6, "six steps above");
 }
 
 // ---------------------------------------------------------------------------
@@ -1094,7 +1113,8 @@ __global__ void __launch_bounds__(256) k_vote_mark(VoteArgs a, float fx, float f
 // and the last block to finish moves the 8 counters into pinned host memory and zeroes them (no
 // memset, no D2H copy on the stream).
 __global__ void __launch_bounds__(256) k_vote_hist(int* marks, const uint8_t* edges, const float* depth, int npix,
-                                                   float dmin, float dmax, int* hist8, unsigned* done, int* host_out) {
+                                                   float dmin, float dmax, int* hist8, unsigned* done, int* host_out,
+                                                   unsigned seq_val) {
   __shared__ int s_h[8];
   __shared__ bool s_last;
   if (threadIdx.x < 8) s_h[threadIdx.x] = 0;
@@ -1119,6 +1139,8 @@ __global__ void __launch_bounds__(256) k_vote_hist(int* marks, const uint8_t* ed
     if (threadIdx.x < 8) host_out[threadIdx.x] = atomicExch(&hist8[threadIdx.x], 0);
     if (threadIdx.x == 0) *done = 0u;
     __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *(volatile int*)&host_out[8] = (int)seq_val;  // the host polls this word
   }
 }
 
@@ -1222,14 +1244,15 @@ void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstri
 }
 
 void launch_vote(const PyrGeom& g, const FramePlanes& curr, int curr_frame, int lvl, int n_clouds, const VoteArgs& va,
-                 int* d_marks, int* d_hist8, unsigned* d_done, int* h_out8, int use_orig_edges, hipStream_t s) {
+                 int* d_marks, int* d_hist8, unsigned* d_done, int* h_out8, unsigned seq_val, int use_orig_edges, hipStream_t s) {
   // d_marks, d_hist8 and d_done are all-zero on entry (zeroed at allocation, left clean by k_vote_hist)
   const LevelGeom& lv = g.lv[lvl];
   if (n_clouds > 0)
     hipLaunchKernelGGL(k_vote_mark, dim3(32, n_clouds), dim3(256), 0, s, va, lv.fx, lv.fy, lv.cx, lv.cy, lv.w, lv.h, d_marks);
   const uint8_t* edges = (use_orig_edges ? curr.edges_orig[lvl] : curr.edges[lvl]) + (size_t)curr_frame * lv.npix;
   hipLaunchKernelGGL(k_vote_hist, dim3(16), dim3(256), 0, s, d_marks, edges,
-                     curr.depth[lvl] + (size_t)curr_frame * lv.npix, lv.npix, g.depth_min, g.depth_max, d_hist8, d_done, h_out8);
+                     curr.depth[lvl] + (size_t)curr_frame * lv.npix, lv.npix, g.depth_min, g.depth_max, d_hist8, d_done, h_out8,
+                     seq_val);
 }
 
 void launch_copy_cloud(float4* dst, const float4* src, int* dst_n, const int* src_n, hipStream_t s) {

@@ -590,7 +590,8 @@ template <bool ONE>
 __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDesc one, const PairDesc* __restrict__ descs,
                                                                    TrackParams prm, revo_pair_result* __restrict__ out,
                                                                    EvalOut* __restrict__ eval_out, u64* __restrict__ mail,
-                                                                   int n_pairs, int cluster, unsigned epoch_base) {
+                                                                   int n_pairs, int cluster, unsigned epoch_base,
+                                                                   unsigned* seq_ptr, unsigned seq_val) {
   __shared__ Cand s_cand[2][KMAX];
   __shared__ PassCtl s_pass[2];
   __shared__ LMState s_st[2];
@@ -1007,6 +1008,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
     r.flags = s.flags;
     r.n_pts0 = d.npts[0];
     out[pair] = r;
+    if (ONE && seq_ptr) {  // the host polls this word in pinned memory instead of waiting for the stream to drain
+      __threadfence_system();
+      *(volatile unsigned*)seq_ptr = seq_val;
+    }
   }
 }
 
@@ -1062,13 +1067,14 @@ void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_res
   const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * NVAL, s);
   const int groups = (n_pairs + 7) / 8;
   hipLaunchKernelGGL(k_track<false>, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, PairDesc{}, d_descs, prm, d_out,
-                     d_eval, (u64*)d_mail, n_pairs, cluster, base);
+                     d_eval, (u64*)d_mail, n_pairs, cluster, base, (unsigned*)nullptr, 0u);
 }
 
 // one pair, descriptor by value; out / eval_out may be device-visible pinned host memory
 void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
-                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s) {
+                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,
+                      hipStream_t s) {
   const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * 2 * (size_t)cluster * NVAL, s);
   hipLaunchKernelGGL(k_track<true>, dim3(8 * cluster), dim3(TRACK_THREADS), 0, s, desc, (const PairDesc*)nullptr, prm, out,
-                     eval_out, (u64*)d_mail, 1, cluster, base);
+                     eval_out, (u64*)d_mail, 1, cluster, base, seq_ptr, seq_val);
 }

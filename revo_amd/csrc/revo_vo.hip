@@ -11,6 +11,12 @@
 extern "C" void revo_ctx_retain_(revo_ctx*);
 extern "C" void revo_ctx_release_(revo_ctx*);
 extern "C" void revo_tracker_reset_past_(revo_ctx*);
+// split single-pair calls (revo_host.hip): launch now, read the result later
+extern "C" int revo_track_launch_(revo_ctx*, const revo_pyr* ref, const revo_pyr* curr, const float R[9], const float T[3], int slot,
+                                  unsigned* seq_out);
+extern "C" int revo_track_wait_(revo_ctx*, int slot, unsigned seq, float R[9], float T[3], float* err, int* status);
+extern "C" int revo_assess_launch_(revo_ctx*, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out);
+extern "C" int revo_assess_wait_(revo_ctx*, int nframes, unsigned seq, int* status);
 
 namespace {
 struct M4 {  // column-major 4x4, Eigen::Matrix4f storage
@@ -47,6 +53,14 @@ struct revo_vo {
   int no_frames = 0, n_keyframes = 0;
   bool just_added_kf = false;
   int hist_level = 2;
+  // look-ahead: the tracker of the NEXT queued frame is launched while this frame's quality vote is still running,
+  // on the assumption that the vote keeps the keyframe (it does for all but a few frames per hundred); a keyframe
+  // change simply ignores that launch.  Same calls, same arguments, same results as the one-at-a-time order.
+  bool spec_valid = false;
+  revo_pyr* spec_pyr = nullptr;
+  int spec_slot = 0;
+  unsigned spec_seq = 0;
+  int slot = 0;  // result slot of the next non-speculative launch
 };
 
 extern "C" int revo_vo_create(revo_ctx* ctx, revo_vo** out) {
@@ -167,11 +181,45 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
   }
   ++v->no_frames;
   float err = 0.f;
-  if ((rc = revo_tracker_track_frames(v->ctx, v->kf.pyr, curr.pyr, v->R, v->T, &err, &status, nullptr, nullptr))) return rc;
+  // trackFrames(kf, curr): already in flight if the previous call looked ahead
+  unsigned seq = 0;
+  int slot = v->slot;
+  if (v->spec_valid && v->spec_pyr == curr.pyr) {
+    slot = v->spec_slot; seq = v->spec_seq;
+  } else {
+    if ((rc = revo_track_launch_(v->ctx, v->kf.pyr, curr.pyr, v->R, v->T, slot, &seq))) return rc;
+  }
+  v->spec_valid = false;
+  if ((rc = revo_track_wait_(v->ctx, slot, seq, v->R, v->T, &err, &status))) return rc;
   M4 T_KF_N = from_RT(v->R, v->T);
   M4 currPoseInWorld = mul(v->kf.T_w_f, T_KF_N);
-  if ((rc = revo_tracker_assess_quality(v->ctx, currPoseInWorld.m, curr.pyr, &status, nullptr, nullptr))) return rc;
+  int nvote = -1;
+  unsigned vseq = 0;
+  if ((rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
+  // what the loop body does when the vote says OK (system.cpp:243-271), computed now so that the next frame's
+  // tracker can start behind the vote kernels instead of behind a host round trip
+  const Pose ok_last{T_KF_N, v->kf.T_w_f};
+  const M4 ok_w1 = ok_last.world();
+  const M4 ok_T_NM1_N = mul(inverse(v->last.world()), ok_w1);
+  float ok_R[9], ok_T[3];
+  to_RT(mul(ok_last.T_kf_curr, ok_T_NM1_N), ok_R, ok_T);
+  {
+    revo_pyr* nxt = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(v->qmu);
+      if (!v->queue.empty()) nxt = v->queue.front().pyr;
+    }
+    if (nxt) {
+      const int sslot = slot ^ 1;
+      unsigned sseq = 0;
+      if (revo_track_launch_(v->ctx, v->kf.pyr, nxt, ok_R, ok_T, sslot, &sseq) == REVO_OK) {
+        v->spec_valid = true; v->spec_pyr = nxt; v->spec_slot = sslot; v->spec_seq = sseq;
+      }
+    }
+  }
+  if ((rc = revo_assess_wait_(v->ctx, nvote, vseq, &status))) return rc;
   if (status == REVO_TRACKER_STATE_NEW_KF && !v->just_added_kf) {  // system.cpp:203-241
+    v->spec_valid = false;  // the look-ahead tracked against the old keyframe: ignored
     revo_pyr* old_kf = v->kf.pyr;
     v->kf = v->prev;
     v->kf.T_w_f = v->last.world();  // kfPyr->setTwf(mPoseGraph.back().getCurrToWorld())
@@ -190,6 +238,7 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
   } else {
     v->just_added_kf = false;
   }
+  v->slot = v->spec_valid ? (v->spec_slot ^ 1) : 0;
   v->before_last = v->last;
   v->last = Pose{T_KF_N, v->kf.T_w_f};  // mPoseGraph.push_back(Pose(T_KF_N, ts, kfPyr))
   if ((rc = revo_tracker_add_old_pcl(v->ctx, curr.pyr, v->hist_level, currPoseInWorld.m, curr.ts))) return rc;

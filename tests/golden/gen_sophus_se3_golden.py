@@ -55,9 +55,20 @@ for a, b in pairs:
     Mb, gb = exp_matrix(b)
     P = (ga * gb).matrix().evalf(30)
     products.append({"a": a, "b": b, "matrix": to_list(P)})
+# SO3: unit quaternion <-> rotation matrix (so3.hpp:280-282 `matrix()`, so3.hpp:419-424 `SO3(R)`), from the reference's
+# sympy So3: q = So3.exp(w).q and its matrix(); the matrix -> quaternion direction is pinned as the inverse of this map
+from sophus.so3 import So3  # noqa: E402
+rot = []
+for w in [[0.3, -0.2, 0.1], [1e-3, 2e-3, -1e-3], [3.0, 0.2, -0.1], [0.0, 3.1, 0.0], [-2.0, -2.0, 0.5], [0.01, 0.0, 0.0],
+          [0.5, 2.9, 0.4], [-0.1, 0.2, 3.0], [2.2, -2.1, 0.3]]:
+    g = So3.exp(sympy.Matrix(3, 1, [sympy.Float(x, 40) for x in w]))
+    q = g.q
+    M = g.matrix().evalf(30)
+    rot.append({"omega": w, "q_wxyz": [float(q.real.evalf(30))] + [float(q.vec[i].evalf(30)) for i in range(3)],
+                "matrix": [[float(M[r, c]) for c in range(3)] for r in range(3)]})
 out = {"source": "thirdparty/Sophus/py/sophus (sympy), test/core/test_se3.cpp:30-43",
-       "exp": cases, "mul": products}
+       "exp": cases, "mul": products, "so3": rot}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sophus_se3_golden.json")
 with open(path, "w") as f:
     json.dump(out, f, indent=1)
-print("wrote", path, len(cases), "exp cases,", len(products), "products")
+print("wrote", path, len(cases), "exp cases,", len(products), "products,", len(rot), "rotations")

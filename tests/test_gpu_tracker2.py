@@ -102,6 +102,33 @@ def test_device_ldlt_matches_the_eigen_restatement_bit_for_bit(api, ro):
     assert n_pivoted > 50  # the pivoting path is what was tested
 
 
+def test_device_quaternion_conversions_against_the_sophus_goldens(api, ro):
+    """Sophus::SE3f(R, T) at every level entry and SO3::matrix() at every level exit (optimizer.cpp:241,308): with
+    zero LM iterations per level the tracker returns matrix(SO3(R_in)) applied once per level -- the device's
+    Eigen Quaternionf(Matrix3f) / toRotationMatrix restatements, fed with the rotation matrices of the reference's
+    sympy So3 (tests/golden/sophus_se3_golden.json) and compared with the oracle's on the same input."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sophus_se3_golden.json")))
+    s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
+    pair = synth.make_pair(2, s)
+    os0 = OptimizerSettings()
+    for i in range(6):
+        os0.max_its_per_lvl[i] = 0
+    ts = TrackerSettings(check_init_values=0)
+    cam, g_ref, g_cur, gt = _pair_objects(api, ro, s, pair, ts, os0)
+    o_ref, o_cur = ro.Pyramid(s, *pair["ref"]), ro.Pyramid(s, *pair["curr"])
+    o_ref.makeKeyframe()
+    ot = ro.Tracker(s, os0, ts)
+    T0 = np.array([0.01, -0.02, 0.03], np.float32)
+    for case in gold["so3"]:
+        R_in = np.array(case["matrix"]).astype(np.float32)
+        st, R_g, T_g, _ = gt.trackFrames(R_in, T0, g_ref, g_cur)
+        r_o = ot.trackFrames(o_ref, o_cur, R_in, T0)
+        assert np.array_equal(R_g, r_o["R"]) and np.array_equal(T_g, r_o["T"]), case["omega"]  # same float operations
+        assert np.allclose(R_g, np.array(case["matrix"]), atol=5e-6), case["omega"]            # and the golden matrix
+        assert gt.last_evals.tolist()[:3] == [1, 1, 1]
+
+
 def _pair_objects(api, ro, s, pair, ts=None, os_=None):
     ts = ts or TrackerSettings()
     if os_ is not None:

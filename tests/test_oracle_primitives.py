@@ -233,6 +233,24 @@ def test_se3_exp_vs_sophus_golden_and_expm():
         assert np.allclose(T, np.array(case["matrix"]), atol=5e-6)
 
 
+def test_so3_matrix_and_quaternion_vs_sophus_golden():
+    """SO3::matrix() (so3.hpp:280-282) and SO3(R) (so3.hpp:419-424, Eigen Quaternionf(Matrix3f)) against the reference's
+    sympy So3: quaternion -> matrix directly, matrix -> quaternion as the inverse map (all four branches of the
+    largest-diagonal selection occur: rotations by ~pi about x, y, z and small ones)."""
+    gold = json.load(open(os.path.join(GOLD, "sophus_se3_golden.json")))
+    branches = set()
+    for case in gold["so3"]:
+        q, M = np.array(case["q_wxyz"]), np.array(case["matrix"])
+        assert np.allclose(ro.quat_to_R(q.astype(np.float32)), M, atol=2e-6), case["omega"]
+        q2 = np.asarray(ro.quat_from_R(M.astype(np.float32)), np.float64)
+        if np.dot(q2, q) < 0:
+            q2 = -q2  # q and -q are the same rotation
+        assert np.allclose(q2, q, atol=3e-6), case["omega"]
+        tr = np.trace(M)
+        branches.add(0 if tr > 0 else 1 + int(np.argmax(np.diag(M))))
+    assert branches == {0, 1, 2, 3}
+
+
 def test_quaternion_roundtrip_and_inverse():
     for seed in range(5):
         r = np.random.default_rng(seed)
