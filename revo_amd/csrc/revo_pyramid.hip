@@ -184,73 +184,88 @@ __device__ __forceinline__ HRow hrow(uint32_t prev, uint32_t m0, uint32_t m1, ui
   return r;
 }
 
-// A row of magnitudes / gradients lives in a VECTOR value, not an array: element access with a constant index is an
-// SSA extract, so "neg ? A[i+1] : A[i-1]" stays a select of two values.  With arrays the optimiser rewrote it as ONE
-// load through a selected POINTER, which pinned the arrays to scratch memory (420 MB of HBM traffic per launch).
-typedef int mrow_t __attribute__((ext_vector_type(16)));        // |grad|^2 of columns -1..8 (10 used)
-typedef uint32_t drow_t __attribute__((ext_vector_type(8)));    // (dx | dy << 16) of columns 0..7
+// A row of magnitudes / gradients is a struct of NAMED scalars, every access spelled with a literal field: the
+// optimiser then sees plain values from the first pass on.  Both an array (indexed inside unrolled loops) and a
+// vector type were pessimised by "select(c, X[i], X[j]) -> X[select(c, i, j)]": the array ended up in scratch
+// memory behind a selected pointer (420 MB of HBM traffic per launch), the vector in 16-deep compare/select chains.
+struct MRow { int v0, v1, v2, v3, v4, v5, v6, v7, v8, v9; };          // |grad|^2 of columns -1..8
+struct DRow { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; };            // (dx | dy << 16) of columns 0..7
 
 // Sobel of the row between a (above) and c (below), b the row itself; cm[]: column masks (0 outside the image)
-__device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm, bool valid, mrow_t& m,
-                                        drow_t& dxy) {
+__device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm, bool valid, MRow& m,
+                                        DRow& dxy) {
+  uint32_t lo[5], hi[5];  // column 2k-1: low halves, column 2k: high halves
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const s2v dx = (a.d[k] + c.d[k]) + (b.d[k] + b.d[k]);
     const s2v dy = c.s[k] - a.s[k];
-    // column 2k-1: low halves, column 2k: high halves
-    const uint32_t lo = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x05040100u);
-    const uint32_t hi = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x07060302u);
-    m[2 * k] = __builtin_amdgcn_sdot2(as_s2(lo), as_s2(lo), 0, false);
-    m[2 * k + 1] = __builtin_amdgcn_sdot2(as_s2(hi), as_s2(hi), 0, false);
-    if (k > 0) dxy[2 * k - 1] = lo;
-    if (k < 4) dxy[2 * k] = hi;
+    lo[k] = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x05040100u);
+    hi[k] = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x07060302u);
   }
   // |grad|^2 outside the image is 0 (cv::Canny pads its magnitude buffer with zeros); columns 0..3 of an
   // active thread are always inside; `valid` is the row's mask (a row above / below the image, an idle thread)
   const uint32_t rv = valid ? ~0u : 0u;
-  m[0] &= (int)(cm[0] & rv);
-#pragma unroll
-  for (int k = 1; k < 5; ++k) m[k] &= (int)rv;
-#pragma unroll
-  for (int k = 5; k < 10; ++k) m[k] &= (int)(cm[k - 4] & rv);
+#define MAG2(x) __builtin_amdgcn_sdot2(as_s2(x), as_s2(x), 0, false)
+  m.v0 = MAG2(lo[0]) & (int)(cm[0] & rv);
+  m.v1 = MAG2(hi[0]) & (int)rv;
+  m.v2 = MAG2(lo[1]) & (int)rv;
+  m.v3 = MAG2(hi[1]) & (int)rv;
+  m.v4 = MAG2(lo[2]) & (int)rv;
+  m.v5 = MAG2(hi[2]) & (int)(cm[1] & rv);
+  m.v6 = MAG2(lo[3]) & (int)(cm[2] & rv);
+  m.v7 = MAG2(hi[3]) & (int)(cm[3] & rv);
+  m.v8 = MAG2(lo[4]) & (int)(cm[4] & rv);
+  m.v9 = MAG2(hi[4]) & (int)(cm[5] & rv);
+#undef MAG2
+  dxy.v0 = hi[0]; dxy.v1 = lo[1]; dxy.v2 = hi[1]; dxy.v3 = lo[2]; dxy.v4 = hi[2]; dxy.v5 = lo[3]; dxy.v6 = hi[3]; dxy.v7 = lo[4];
 }
 
-// NMS of one row (cv::Canny): 8 candidate bits and 8 strong bits.  A, B, C: |grad|^2 of the rows above, at and
-// below; dxy: the row's own gradients
-__device__ __forceinline__ void nms_row(const mrow_t& A, const mrow_t& B, const mrow_t& C, const drow_t& dxyB, int low, int high,
-                                        uint32_t* cand, uint32_t* strong) {
+// NMS of one pixel (cv::Canny): its 3x3 neighbourhood of |grad|^2 by value, its own gradient; sets bit k of cand / strong
+__device__ __forceinline__ void nms_px(int k, int aL, int aM, int aR, int bL, int m, int bR, int cL, int cM, int cR, uint32_t dxy,
+                                       int low, int high, uint32_t& cb, uint32_t& sb) {
   const int TG22 = 13573;  // (int)(0.41421356...*(1<<15) + 0.5)
+  const s2v v = as_s2(dxy);
+  const s2v z = {0, 0};
+  const uint32_t ab = as_u32(__builtin_elementwise_max(v, z - v));  // |dx| | |dy| << 16
+  const int ax = (int)(ab & 0xffffu);
+  const int ay15 = (int)((ab >> 1) & 0x7fff8000u);                  // |dy| << 15
+  const int t22 = ax * TG22;
+  const bool horiz = ay15 < t22;
+  const bool vert = ay15 > t22 + (ax << 16);
+  const bool neg = (int)(dxy ^ (dxy << 16)) < 0;                    // sign(dx) != sign(dy)
+  const int diag_a = neg ? aR : aL;
+  const int diag_b = neg ? cL : cR;
+  const int a = horiz ? bL : (vert ? aM : diag_a);
+  const int b = horiz ? bR : (vert ? cM : diag_b);
+  const bool ge = horiz || vert;                                    // m > a && m >= b on the axes, m > both on the diagonals
+  const bool is_max = (m > a) & (ge ? (m >= b) : (m > b));
+  const bool c = (m > low) & is_max;
+  cb |= c ? (1u << k) : 0u;
+  sb |= (c & (m > high)) ? (1u << k) : 0u;
+}
+// NMS of one row: 8 candidate bits and 8 strong bits.  A, B, C: |grad|^2 of the rows above, at and below; d: the row's gradients
+__device__ __forceinline__ void nms_row(const MRow& A, const MRow& B, const MRow& C, const DRow& d, int low, int high,
+                                        uint32_t* cand, uint32_t* strong) {
   uint32_t cb = 0, sb = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = k + 1;
-    const int m = B[i];
-    const uint32_t dxy = dxyB[k];
-    const s2v v = as_s2(dxy);
-    const s2v z = {0, 0};
-    const uint32_t ab = as_u32(__builtin_elementwise_max(v, z - v));  // |dx| | |dy| << 16
-    const int ax = (int)(ab & 0xffffu);
-    const int ay15 = (int)((ab >> 1) & 0x7fff8000u);                  // |dy| << 15
-    const int t22 = ax * TG22;
-    const bool horiz = ay15 < t22;
-    const bool vert = ay15 > t22 + (ax << 16);
-    const bool neg = (int)(dxy ^ (dxy << 16)) < 0;                    // sign(dx) != sign(dy)
-    const int diag_a = neg ? A[i + 1] : A[i - 1];
-    const int diag_b = neg ? C[i - 1] : C[i + 1];
-    const int a = horiz ? B[i - 1] : (vert ? A[i] : diag_a);
-    const int b = horiz ? B[i + 1] : (vert ? C[i] : diag_b);
-    const bool ge = horiz || vert;                                    // m > a && m >= b on the axes, m > both on the diagonals
-    const bool is_max = (m > a) && (ge ? (m >= b) : (m > b));
-    const bool c = (m > low) && is_max;
-    cb |= c ? (1u << k) : 0u;
-    sb |= (c && m > high) ? (1u << k) : 0u;
-  }
+  nms_px(0, A.v0, A.v1, A.v2, B.v0, B.v1, B.v2, C.v0, C.v1, C.v2, d.v0, low, high, cb, sb);
+  nms_px(1, A.v1, A.v2, A.v3, B.v1, B.v2, B.v3, C.v1, C.v2, C.v3, d.v1, low, high, cb, sb);
+  nms_px(2, A.v2, A.v3, A.v4, B.v2, B.v3, B.v4, C.v2, C.v3, C.v4, d.v2, low, high, cb, sb);
+  nms_px(3, A.v3, A.v4, A.v5, B.v3, B.v4, B.v5, C.v3, C.v4, C.v5, d.v3, low, high, cb, sb);
+  nms_px(4, A.v4, A.v5, A.v6, B.v4, B.v5, B.v6, C.v4, C.v5, C.v6, d.v4, low, high, cb, sb);
+  nms_px(5, A.v5, A.v6, A.v7, B.v5, B.v6, B.v7, C.v5, C.v6, C.v7, d.v5, low, high, cb, sb);
+  nms_px(6, A.v6, A.v7, A.v8, B.v6, B.v7, B.v8, C.v6, C.v7, C.v8, d.v6, low, high, cb, sb);
+  nms_px(7, A.v7, A.v8, A.v9, B.v7, B.v8, B.v9, C.v7, C.v8, C.v9, d.v7, low, high, cb, sb);
   *cand = cb;
   *strong = sb;
 }
 
 #define NMS_R 6
-__global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
+#ifdef NMS_WAVES_PER_EU
+#define NMS_OCC __attribute__((amdgpu_waves_per_eu(NMS_WAVES_PER_EU, NMS_WAVES_PER_EU)))
+#else
+#define NMS_OCC
+#endif
+__global__ void __launch_bounds__(256) NMS_OCC k_canny_nms(PyrGeom g, FramePlanes pl) {
   const int f = g.frame0 + blockIdx.z;
   const int l = level_of(g, blockIdx.x, &LevelGeom::nms_block_base);
   const LevelGeom& lv = g.lv[l];
@@ -271,27 +286,38 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   cm[0] = (active && has_prev) ? ~0u : 0u;
 #pragma unroll
   for (int k = 1; k < 6; ++k) cm[k] = (active && x + 3 + k < w) ? ~0u : 0u;
-  auto load_hrow = [&](int r) -> HRow {
+  // A row arrives as four raw words (columns -4..11); the words of the row a step needs are requested one step ahead,
+  // so a wave waits for memory once, not once per row (the steps are long basic blocks the scheduler does not move
+  // loads across: at one or two waves per SIMD next to a tracker every wait was a full round trip).
+  struct Raw { uint32_t prev, m0, m1, next; };
+  auto load_raw = [&](int r) -> Raw {
     const int rr = clampi(r, 0, h - 1);  // BORDER_REPLICATE
     const uint8_t* row = gray + (size_t)rr * w;
-    const uint32_t m0 = *reinterpret_cast<const uint32_t*>(row + xo);
-    uint32_t prev = *reinterpret_cast<const uint32_t*>(row + o_prev);
-    uint32_t m1 = *reinterpret_cast<const uint32_t*>(row + o_m1);
-    uint32_t next = *reinterpret_cast<const uint32_t*>(row + o_next);
-    if (!has_prev) prev = (m0 & 0xffu) * 0x01010101u;
-    if (!has_m1) m1 = (m0 >> 24) * 0x01010101u;
-    if (!has_next) next = (m1 >> 24) * 0x01010101u;
-    return hrow(prev, m0, m1, next);
+    Raw q;
+    q.m0 = *reinterpret_cast<const uint32_t*>(row + xo);
+    q.prev = *reinterpret_cast<const uint32_t*>(row + o_prev);
+    q.m1 = *reinterpret_cast<const uint32_t*>(row + o_m1);
+    q.next = *reinterpret_cast<const uint32_t*>(row + o_next);
+    return q;
   };
-  // Three gray rows (H*) and three magnitude rows (M*, D*) in flight, as separately named arrays picked with
-  // compile-time indices: nothing moves, nothing is indexed dynamically (2-D arrays indexed through a run-time-looking
-  // expression were left in scratch memory by the compiler: 420 MB of HBM traffic per launch instead of 33).
+  auto make_hrow = [&](Raw q) -> HRow {
+    if (!has_prev) q.prev = (q.m0 & 0xffu) * 0x01010101u;
+    if (!has_m1) q.m1 = (q.m0 >> 24) * 0x01010101u;
+    if (!has_next) q.next = (q.m1 >> 24) * 0x01010101u;
+    return hrow(q.prev, q.m0, q.m1, q.next);
+  };
+  // Three gray rows (H*) and three magnitude rows (M*, D*) in flight, as separately named values picked with
+  // compile-time indices: nothing moves, nothing is indexed dynamically.
   HRow H0, H1, H2;
-  mrow_t M0 = 0, M1 = 0, M2 = 0;
-  drow_t D0 = 0, D1 = 0, D2 = 0;
-  H0 = load_hrow(y0 - 2); H1 = load_hrow(y0 - 1); H2 = load_hrow(y0);
-  mag_row(H0, H1, H2, cm, active && y0 - 1 >= 0, M0, D0);                  // magnitude row y0 - 1
-  H0 = load_hrow(y0 + 1);
+  MRow M0, M1, M2;
+  DRow D0, D1, D2;
+  {
+    const Raw r0 = load_raw(y0 - 2), r1 = load_raw(y0 - 1), r2 = load_raw(y0), r3 = load_raw(y0 + 1);
+    H0 = make_hrow(r0); H1 = make_hrow(r1); H2 = make_hrow(r2);
+    mag_row(H0, H1, H2, cm, active && y0 - 1 >= 0, M0, D0);                // magnitude row y0 - 1
+    H0 = make_hrow(r3);
+  }
+  Raw ahead = load_raw(y0 + 2);
   mag_row(H1, H2, H0, cm, active, M1, D1);                                 // magnitude row y0
   uint2* out = pl.cs[l] + ((size_t)f * h + y0) * lv.wpr + (xg >> 2);
   const int sh = 8 * (threadIdx.x & 3);
@@ -308,7 +334,8 @@ __global__ void __launch_bounds__(256) k_canny_nms(PyrGeom g, FramePlanes pl) {
   // (Ma, Mb), row y0+i+1 goes to Mc
 #define NMS_STEP(i, Ha, Hb, Hc, Ma, Mb, Mc, Db, Dc)                                   \
   {                                                                                   \
-    Hc = load_hrow(y0 + (i) + 2);                                                     \
+    Hc = make_hrow(ahead);                                                            \
+    if ((i) < NMS_R - 1) ahead = load_raw(y0 + (i) + 3);                              \
     mag_row(Ha, Hb, Hc, cm, active && y0 + (i) + 1 < h, Mc, Dc);                      \
     uint32_t cb, sb;                                                                  \
     nms_row(Ma, Mb, Mc, Db, g.canny_low, g.canny_high, &cb, &sb);                     \
@@ -362,7 +389,12 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
 #define HA(i)
 #endif
 template <bool C_IN_LDS>
-__global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl) {
+#ifdef HYST_NUM_VGPR
+#define HYST_OCC __attribute__((amdgpu_num_vgpr(HYST_NUM_VGPR)))
+#else
+#define HYST_OCC
+#endif
+__global__ void __launch_bounds__(HYST_THREADS) HYST_OCC k_hyst(PyrGeom g, FramePlanes pl) {
   extern __shared__ uint32_t s_mem[];
 #ifdef REVO_HYST_PROFILE
   long long hp[12], ha[8], hlast = 0;

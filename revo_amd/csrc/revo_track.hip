@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   __shared__ float s_part[NWAVES][NVAL];
   __shared__ int s_evals[REVO_L];  // residual evaluations per level, in the reference's count (wave 0 / lane 0 only)
 #ifdef REVO_TRACK_PROFILE
-  __shared__ long long s_prof[12];
+  __shared__ long long s_prof[12 + 2 * REVO_L];  // [12 + l]: cycles spent in level l, [12 + REVO_L + l]: its passes
 #define PROF_MARK(var) const long long var = clock64()
 #else
 #define PROF_MARK(var)
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       }
       s_pass[0] = pc;
 #ifdef REVO_TRACK_PROFILE
-      for (int i = 0; i < 12; ++i) s_prof[i] = 0;
+      for (int i = 0; i < 12 + 2 * REVO_L; ++i) s_prof[i] = 0;
 #endif
     }
   }
@@ -971,6 +971,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       const long long tp6 = clock64();
       s_prof[0] += tp1 - tp0; s_prof[1] += tp2 - tp1; s_prof[2] += tp3 - tp2; s_prof[3] += 0; s_prof[4] += tp5 - tp3;
       s_prof[5] += tp6 - tp5;
+      s_prof[12 + l] += tp6 - tp0; s_prof[12 + REVO_L + l] += 1;
     }
 #endif
   }
@@ -1003,6 +1004,11 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       EvalOut& eo = eval_out[pair];
       for (int i = 0; i < 12; ++i) eo.A[i] = (float)s_prof[i];
       eo.A[12] = (float)p;
+      for (int i = 0; i < 2 * REVO_L; ++i) eo.A[13 + i] = (float)s_prof[12 + i];
+    } else {  // batches have no EvalOut: the per-level split replaces the pose of the record (profile builds only)
+      for (int i = 0; i < 4; ++i) { r.R[i] = (float)s_prof[12 + i]; r.R[4 + i] = (float)s_prof[12 + REVO_L + i]; }
+      r.R[8] = (float)s_prof[6]; r.T[0] = (float)s_prof[7]; r.T[1] = (float)s_prof[8]; r.T[2] = (float)s_prof[9];
+      r.err = (float)s_prof[10];
     }
 #endif
     r.flags = s.flags;
