@@ -369,7 +369,9 @@ __global__ void __launch_bounds__(256) NMS_OCC k_canny_nms(PyrGeom g, FramePlane
 // imgpyramidrgbd.cpp:185-195) and generateDistHistogram's tile counts (imgpyramidrgbd.cpp:146-172; u8
 // counters wrap like the reference's ++ on uchar) straight from the bitmap.
 // ---------------------------------------------------------------------------
+#ifndef HYST_THREADS
 #define HYST_THREADS 1024
+#endif
 __device__ __forceinline__ uint32_t dil3(uint32_t a, uint32_t al, uint32_t ar) {
   // a | a << 1 | a >> 1 with the neighbour words' edge bits shifted in
   return a | __builtin_amdgcn_alignbit(a, al, 31) | __builtin_amdgcn_alignbit(ar, a, 1);
@@ -403,19 +405,30 @@ __global__ void __launch_bounds__(HYST_THREADS) HYST_OCC k_hyst(PyrGeom g, Frame
   int dbg_sweeps = 0, dbg_bands = 0;
 #endif
   HP(0);
-  const int f = g.frame0 + blockIdx.z;
-  const int l = blockIdx.x;
+  // 1-D grid, level-major: workgroup ids go round-robin over the 8 XCDs, and with (level, frame) = (x, z) every
+  // level-0 workgroup -- the expensive ones -- had an id that is a multiple of n_levels = 4: all of them on XCDs 0
+  // and 4, where a co-running tracker leaves 8 CUs each (200 us per launch instead of 80).  Heaviest level first.
+  const int nB = gridDim.x / g.n_levels;
+  const int l = blockIdx.x / nB;
+  const int f = g.frame0 + blockIdx.x % nB;
   const LevelGeom& lv = g.lv[l];
   const int w = lv.w, h = lv.h, wpr = lv.wpr;
   const int pitch = wpr;                         // one zero row above and below (+ one pad word in front / behind)
-  uint32_t* E = s_mem + 1;                       // E[(r + 1) * pitch + c] = E(r, c), r = -1 .. h
+  const int nwords = h * wpr;
   const int e_words = (h + 2) * pitch + 2;
-  uint32_t* Cl = s_mem + e_words;                // h x wpr (C_IN_LDS)
+  // C_IN_LDS: [Cl: the weak candidates, h x wpr] [union-find tables ...] ... [E, at the top]; otherwise E alone.
+  // The union-find tables of a level with very many weak runs (a low-contrast 640x480 frame has ~10k) grow over
+  // E: E is not needed while runs are linked, and is rebuilt as S | (C & ~Cl) from the NMS words (L2) before the
+  // flag pass.  That keeps such a level in ONE band (two sweeps over three bands cost those frames -- and with
+  // them the whole launch -- twice the time); levels with fewer runs never re-read anything.
+  uint32_t* Cl = s_mem;
+  uint32_t* Ebase = C_IN_LDS ? s_mem + (REVO_HYST_LDS_MAX / 4 - e_words) : s_mem;
+  uint32_t* E = Ebase + 1;                       // E[(r + 1) * pitch + c] = E(r, c), r = -1 .. h
   const uint2* cs = pl.cs[l] + (size_t)f * h * wpr;
   const int tid = threadIdx.x;
   // the zero rows above / below the level and the two pad words; everything between is written by the load
-  for (int i = tid; i < pitch + 1; i += HYST_THREADS) { s_mem[i] = 0u; s_mem[e_words - 1 - i] = 0u; }
-  for (int i = tid; i < h * wpr; i += HYST_THREADS) {
+  for (int i = tid; i < pitch + 1; i += HYST_THREADS) { Ebase[i] = 0u; Ebase[e_words - 1 - i] = 0u; }
+  for (int i = tid; i < nwords; i += HYST_THREADS) {
     const uint2 v = cs[i];
     E[pitch + i] = v.y;
     if (C_IN_LDS) Cl[i] = v.x & ~v.y;  // the WEAK candidates (C = Cl | S, and E holds S or more at all times)
@@ -437,10 +450,12 @@ __global__ void __launch_bounds__(HYST_THREADS) HYST_OCC k_hyst(PyrGeom g, Frame
   int dbg_runs = -1;
 #endif
   if (C_IN_LDS) {
-    const int nwords = h * wpr;
     unsigned short* Bs = reinterpret_cast<unsigned short*>(Cl + nwords);          // runs before word i (nwords + 1 entries)
     uint32_t* parent = Cl + nwords + (nwords + 2) / 2;
-    const int cap = ((int)(REVO_HYST_LDS_MAX / 4) - (e_words + nwords + (nwords + 2) / 2)) / 2;  // runs that fit (parent + rec)
+    // runs that fit: parent + rec while linking (over E if need be), the parents next to E afterwards
+    const int table_words = (int)(REVO_HYST_LDS_MAX / 4) - (nwords + (nwords + 2) / 2);
+    const int cap = min(table_words / 2, table_words - e_words);
+    const int cap_keep = (table_words - e_words) / 2;  // up to here the tables end below E
     __shared__ int s_wsum[HYST_THREADS / 64];
     __shared__ int s_total, s_promoted;
     auto weak = [&](int wi) -> uint32_t { return Cl[wi]; };
@@ -576,29 +591,56 @@ __global__ void __launch_bounds__(HYST_THREADS) HYST_OCC k_hyst(PyrGeom g, Frame
         for (int me = tid; me < nr; me += HYST_THREADS) parent[me] = key_of(find(me));
         __syncthreads();
         HA(3);
-        // components that touch an edge pixel (strong, or promoted in another band): flag the root
-        for (int me = tid; me < nr; me += HYST_THREADS) {
-          int wi; uint32_t run;
-          run_at(me, &wi, &run);
+        if (nr > cap_keep) {  // the run records grew over E: rebuild it (they are dead now)
+          for (int i = tid; i < pitch + 1; i += HYST_THREADS) { Ebase[i] = 0u; Ebase[e_words - 1 - i] = 0u; }
+          for (int i0 = tid; i0 < nwords; i0 += 5 * HYST_THREADS) {  // five loads in flight, not one round trip per word
+            uint2 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = cs[min(i0 + k * HYST_THREADS, nwords - 1)];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const int i = i0 + k * HYST_THREADS;
+              if (i < nwords) E[pitch + i] = v[k].y | (v[k].x & ~Cl[i]);
+            }
+          }
+          __syncthreads();
+        }
+        // components that touch an edge pixel (strong, or promoted in another band): flag the root.  Words (not
+        // runs) are dealt to the threads here: one neighbourhood per word, its runs found from the bitmap
+        for (int wi = wa + tid; wi < wb; wi += HYST_THREADS) {
+          const uint32_t wk = weak(wi);
+          if (!wk) continue;
           int r = (int)(((float)wi + 0.5f) * inv_wpr);
           r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
           const int c = wi - r * wpr;
           const uint32_t lm = c > 0 ? ~0u : 0u, rm = c < wpr - 1 ? ~0u : 0u;
-          const uint32_t* Ec = E + pitch + wi;
-          const uint32_t sd = dil3(Ec[-pitch], Ec[-pitch - 1] & lm, Ec[-pitch + 1] & rm) | dil3(Ec[pitch], Ec[pitch - 1] & lm, Ec[pitch + 1] & rm) |
-                              __builtin_amdgcn_alignbit(Ec[0], Ec[-1] & lm, 31) | __builtin_amdgcn_alignbit(Ec[1] & rm, Ec[0], 1);
-          if (run & sd) atomicOr(&parent[find(me)], FLAG);
+          const uint32_t* Xc = E + pitch + wi;
+          const uint32_t sd = dil3(Xc[-pitch], Xc[-pitch - 1] & lm, Xc[-pitch + 1] & rm) | dil3(Xc[pitch], Xc[pitch - 1] & lm, Xc[pitch + 1] & rm) |
+                              __builtin_amdgcn_alignbit(Xc[0], Xc[-1] & lm, 31) | __builtin_amdgcn_alignbit(Xc[1] & rm, Xc[0], 1);
+          if (!(wk & sd)) continue;
+          const uint32_t touched = run_fill(wk, wk & sd);  // the runs of the word that touch an edge pixel
+          int me = (int)Bs[wi] - id0;
+          for (uint32_t m = starts(wk); m; m &= m - 1, ++me)
+            if (touched & m & (0u - m)) {
+              uint32_t* root = &parent[parent[me] & 0xffffu];  // parent[me] is the root's key since the flattening pass
+              if (!(*root & FLAG)) atomicOr(root, FLAG);      // (a big component is flagged by hundreds of runs: read first)
+            }
         }
         __syncthreads();
         HA(4);
-        // a weak run is an edge iff its root is flagged: it moves from the weak bitmap to E
+        // a weak run is an edge iff its root is flagged: it leaves the weak bitmap (E = S | (C & ~Cl))
         bool any = false;
-        for (int me = tid; me < nr; me += HYST_THREADS) {
-          if (!(parent[parent[me] & 0xffffu] & FLAG)) continue;  // parent[me] is the root's key since the flattening pass
-          int wi; uint32_t run;
-          run_at(me, &wi, &run);
-          atomicOr(&E[pitch + wi], run);
-          atomicAnd(&Cl[wi], ~run);
+        for (int wi = wa + tid; wi < wb; wi += HYST_THREADS) {
+          const uint32_t wk = weak(wi);
+          if (!wk) continue;
+          int me = (int)Bs[wi] - id0;
+          uint32_t prom = 0;
+          for (uint32_t m = starts(wk); m; m &= m - 1, ++me)
+            if (parent[parent[me] & 0xffffu] & FLAG) prom |= m & (0u - m);
+          if (!prom) continue;
+          const uint32_t runs = run_fill(wk, prom);
+          Cl[wi] = wk & ~runs;      // this thread owns the word in this pass: plain stores
+          E[pitch + wi] |= runs;
           // a promotion can only reach a band that this sweep has ALREADY closed through the band's first row
           any = any || (r0 > 0 && wi < wa + wpr);
         }
@@ -929,7 +971,8 @@ __device__ __forceinline__ int block_exclusive_scan(int* a, int n, int* s_part) 
 
 __global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl) {
   __shared__ int s_part[1024];
-  const int f = g.frame0 + blockIdx.z, l = blockIdx.x;
+  const int nB = gridDim.x / g.n_levels;  // level-major 1-D grid (see k_hyst: spreads the big level over all XCDs)
+  const int f = g.frame0 + blockIdx.x % nB, l = blockIdx.x / nB;
   const int n = g.lv[l].w * g.lv[l].nchunk;
   const int total = block_exclusive_scan(pl.chunk[l] + (size_t)f * n, n, s_part);
   if (threadIdx.x == 0) pl.npts[f * REVO_L + l] = total;
@@ -1223,9 +1266,9 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
     attr_set = true;
   }
   if (ec_bytes + 4096 <= REVO_HYST_LDS_MAX)  // candidate bitmap + union-find labels in LDS: all of it (one workgroup per CU anyway)
-    hipLaunchKernelGGL(k_hyst<true>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p);
+    hipLaunchKernelGGL(k_hyst<true>, dim3(g.n_levels * B), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p);
   else  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
-    hipLaunchKernelGGL(k_hyst<false>, dim3(g.n_levels, 1, B), dim3(HYST_THREADS), e_bytes, s, g, p);
+    hipLaunchKernelGGL(k_hyst<false>, dim3(g.n_levels * B), dim3(HYST_THREADS), e_bytes, s, g, p);
 }
 
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
@@ -1237,7 +1280,7 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid(g.total_strips, 1, B);
   hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
-  hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels, 1, B), dim3(1024), 0, s, g, p);
+  hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
 }
 
