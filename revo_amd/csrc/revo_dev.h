@@ -26,7 +26,8 @@ struct LevelGeom {
   int nms_block_base;  // first block of this level in the k_canny_nms launch
   int has_orig;        // fillInEdges may change this level: edgesOrigPyr is a separate plane (imgpyramidrgbd.cpp:185-195)
   int pix_base;        // sum of npix of finer levels
-  int row_base;        // sum of h of finer levels
+  int edt_rows;        // rows one k_edt_rows workgroup handles (about EDT_ROW_PX pixels)
+  int edt_block_base;  // first block of this level in the k_edt_rows launch
   int strip_base;      // number of 64-column strips of finer levels (compaction launch decode)
   int cc_base;         // sum of w*nchunk of finer levels
 };
@@ -34,7 +35,7 @@ struct LevelGeom {
 struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
-  int total_nms_blocks, total_pix, total_rows, total_strips, total_cc;
+  int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
   int use_edge_hist;
@@ -98,6 +99,7 @@ struct EvalOut {
 
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
 #define NMS_ROWS 6                  // output rows per k_canny_nms thread (8 pixels wide)
+#define EDT_ROW_PX 1280             // pixels per k_edt_rows workgroup (whole rows)
 #define REVO_HYST_LDS_MAX 158720    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
 #ifndef TRACK_THREADS
 #define TRACK_THREADS 512

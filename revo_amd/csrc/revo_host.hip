@@ -187,13 +187,14 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     // the level's edge bitmap must fit the LDS of one workgroup (k_hyst)
     if (((size_t)(v.h + 2) * v.wpr + 2) * 4 > REVO_HYST_LDS_MAX) { *why = "image too large: (height + 2) x ceil(width/32) bitmap words must fit 155 KB of LDS"; return -1; }
     v.pix_base = pix; pix += v.npix;
-    v.row_base = row; row += v.h;
+    v.edt_rows = std::max(1, EDT_ROW_PX / v.w);
+    v.edt_block_base = row; row += (v.h + v.edt_rows - 1) / v.edt_rows;
     v.strip_base = col; col += (v.w + 63) / 64;
     v.cc_base = cc; cc += v.w * v.nchunk;
   }
   for (int l = 1; l < L; ++l)  // fillInEdges' gate (imgpyramidrgbd.cpp:188-195 + the patch sizes that exist)
     g->lv[l].has_orig = (s.use_edge_hist && g->lv[l].patch > 0 && g->lv[l - 1].patch > 0) ? 1 : 0;
-  g->total_nms_blocks = tile; g->total_pix = pix; g->total_rows = row; g->total_strips = col; g->total_cc = cc;
+  g->total_nms_blocks = tile; g->total_pix = pix; g->total_edt_blocks = row; g->total_strips = col; g->total_cc = cc;
   return 0;
 }
 

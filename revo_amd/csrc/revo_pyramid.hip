@@ -1096,7 +1096,7 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
   int above = -EDT_INF, below = EDT_INF;  // nearest edge rows outside this segment
   for (int k = 0; k < grp; ++k) above = max(above, s_last[k * ncols + col]);
   for (int k = ngroups - 1; k > grp; --k) below = min(below, s_first[k * ncols + col]);
-  int* g2 = pl.scratch[l] + (size_t)f * lv.npix;
+  uint16_t* gd = reinterpret_cast<uint16_t*>(pl.scratch[l]) + (size_t)f * lv.npix;  // vertical distance, 0xffff = no edge in the column
   for (int y = yb; y < ye; ++y) {
     const int k = y - yb;
     const unsigned lo = em & (0xffffffffu >> (31 - k));  // bits 0..k: edges at or above y (inside the segment)
@@ -1106,39 +1106,55 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
     const int d_up = (up <= -EDT_INF) ? EDT_INF : (y - up);
     const int d_dn = (dn >= EDT_INF) ? EDT_INF : (dn - y);
     const int m = min(d_up, d_dn);
-    g2[(size_t)y * lv.w + x] = m >= EDT_INF ? EDT_INF : m * m;
+    gd[(size_t)y * lv.w + x] = (uint16_t)(m >= EDT_INF ? 0xffff : m);  // height <= 1024
   }
 }
 
-#define EDT_MAXW REVO_MAX_WIDTH
+// Rows: a workgroup takes whole rows worth ~EDT_ROW_PX pixels (2 rows of 640, 16 of 80: every lane has a pixel;
+// one workgroup per row left 70 % of the lanes of the small levels idle), squares the vertical distances into LDS
+// rows padded with "no edge" on both sides as far as the search can reach, and every pixel searches outwards
+//      d2(x) = min_d  d^2 + min(g2[x - d], g2[x + d]),     four distances per trip, until d^2 >= best
+// with no bounds checks (round 1: two compares + two selects per sample, 30 M VALU + 28 M SALU per launch).
 __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int f0, int fstride) {
-  __shared__ int s_g2[EDT_MAXW];
+  extern __shared__ int s_g2[];
   const int f = f0 + blockIdx.z * fstride;
-  const int l = level_of(g, blockIdx.x, &LevelGeom::row_base);
+  const int l = level_of(g, blockIdx.x, &LevelGeom::edt_block_base);
   const LevelGeom lv = g.lv[l];
-  const int y = blockIdx.x - lv.row_base;
   const int w = lv.w;
-  const int* g2 = pl.scratch[l] + (size_t)f * lv.npix + (size_t)y * w;
-  for (int x = threadIdx.x; x < w; x += 256) s_g2[x] = g2[x];
+  const int y0 = (blockIdx.x - lv.edt_block_base) * lv.edt_rows;
+  const int nr = min(lv.edt_rows, lv.h - y0);
+  const int pad = w + 4, pitch = w + 2 * pad;  // the search stops at d < w (+3 for the trip): never leaves the padding
+  const uint16_t* gd = reinterpret_cast<const uint16_t*>(pl.scratch[l]) + (size_t)f * lv.npix + (size_t)y0 * w;
+  const float inv_pitch = 1.0f / (float)pitch, inv_w = 1.0f / (float)w;
+  for (int i = threadIdx.x; i < nr * pitch; i += 256) {
+    int r = (int)(((float)i + 0.5f) * inv_pitch);
+    r += (r + 1) * pitch <= i ? 1 : (r * pitch > i ? -1 : 0);
+    const int c = i - r * pitch - pad;
+    int v = EDT_INF;
+    if (c >= 0 && c < w) {
+      const int d = gd[r * w + c];
+      v = d == 0xffff ? EDT_INF : d * d;
+    }
+    s_g2[i] = v;
+  }
   __syncthreads();
-  float* dt = pl.dt[l] + (size_t)f * lv.npix + (size_t)y * w;
-  for (int x = threadIdx.x; x < w; x += 256) {
-    int best = s_g2[x];
-    // four distances per trip: eight independent LDS reads, one dependent min chain; the loop control
-    // (per-lane exit -> exec-mask bookkeeping on the scalar unit) was the bound with two (PMC: 35 M SALU
-    // vs 32 M VALU per launch).  Distances past the exit bound cannot win, so the result is unchanged.
-    for (int d = 1; d < w; d += 4) {
-      if (d * d >= best) break;
+  float* dt = pl.dt[l] + (size_t)f * lv.npix + (size_t)y0 * w;
+  for (int p = threadIdx.x; p < nr * w; p += 256) {
+    int r = (int)(((float)p + 0.5f) * inv_w);
+    r += (r + 1) * w <= p ? 1 : (r * w > p ? -1 : 0);
+    const int x = p - r * w;
+    const int* c = s_g2 + r * pitch + pad + x;
+    int best = c[0];
+    for (int d = 1; d < w && d * d < best; d += 4) {
       int m = best;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int dj = d + j, ddj = dj * dj;
-        const int a = (x - dj >= 0) ? s_g2[x - dj] : EDT_INF, b = (x + dj < w) ? s_g2[x + dj] : EDT_INF;
-        m = min(m, ddj + min(a, b));
+        const int dj = d + j;
+        m = min(m, dj * dj + min(c[-dj], c[dj]));
       }
       best = m;
     }
-    dt[x] = best >= EDT_INF ? sqrtf(1e15f) : sqrtf((float)best);
+    dt[p] = best >= EDT_INF ? sqrtf(1e15f) : sqrtf((float)best);
   }
 }
 
@@ -1309,7 +1325,9 @@ void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride
     strips += (g.lv[l].w + ncols - 1) / ncols;
   }
   hipLaunchKernelGGL(k_edt_cols, dim3(strips, 1, count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride);
-  hipLaunchKernelGGL(k_edt_rows, dim3(g.total_rows, 1, count), dim3(256), 0, s, g, p, f0, fstride);
+  size_t rows_lds = 0;
+  for (int l = 0; l < g.n_levels; ++l) rows_lds = std::max(rows_lds, (size_t)g.lv[l].edt_rows * (3 * g.lv[l].w + 8) * sizeof(int));
+  hipLaunchKernelGGL(k_edt_rows, dim3(g.total_edt_blocks, 1, count), dim3(256), rows_lds, s, g, p, f0, fstride);
 }
 
 // The float4 table is only materialised for the returnOptimizationStructure accessor: the
