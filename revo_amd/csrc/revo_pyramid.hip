@@ -853,11 +853,15 @@ __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
 // HBM coalesced.  (Thread-per-slot with direct stores measured 10x write amplification on the slot
 // arrays and 3x on the points: WRITE_SIZE 45 MB and 68 MB for 5 MB and 23 MB of data.)
 #define CW_COLS 64
-#define CW_LANES 16                    // chunk lanes per block (1024 threads); levels with more chunks loop
+#define CW_LANES 16                    // chunk lanes per block of the write pass (1024 threads); levels with more chunks loop
+#ifndef CW_LANES_COUNT
+#define CW_LANES_COUNT 8               // count pass: 512 threads x 48 VGPRs fit next to a resident tracker workgroup (176 free
+#endif                                 // VGPRs per SIMD); 1024 x 48 do not, and the pass then waited for the tracker's CUs
 #define CW_MAXCHUNK 32                 // height <= 1024
 #define CW_STAGE 4096                  // points staged in LDS per strip (64 KB); denser strips store directly
 template <bool WRITE>
-__global__ void __launch_bounds__(CW_COLS * CW_LANES) k_compact_walk(PyrGeom g, FramePlanes pl) {
+__global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT)) k_compact_walk(PyrGeom g, FramePlanes pl) {
+  constexpr int LANES = WRITE ? CW_LANES : CW_LANES_COUNT;
   __shared__ int s_cnt[CW_COLS * CW_MAXCHUNK];        // count pass: counts; write pass: offsets
   __shared__ unsigned s_mask[CW_COLS * CW_MAXCHUNK];
   __shared__ float4 s_pts[WRITE ? CW_STAGE : 1];
@@ -876,7 +880,7 @@ __global__ void __launch_bounds__(CW_COLS * CW_LANES) k_compact_walk(PyrGeom g, 
     // validity of the 32 rows is kept as a bit mask for the write pass
     const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
     if (x < lv.w) {
-      for (int c = cl; c < lv.nchunk; c += CW_LANES) {
+      for (int c = cl; c < lv.nchunk; c += LANES) {
         const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
         unsigned em = 0;
 #pragma unroll 8
@@ -903,12 +907,12 @@ __global__ void __launch_bounds__(CW_COLS * CW_LANES) k_compact_walk(PyrGeom g, 
       }
     }
     __syncthreads();
-    for (int i = tid; i < nslots; i += CW_COLS * CW_LANES) {
+    for (int i = tid; i < nslots; i += CW_COLS * LANES) {
       pl.cmask[l][slot0 + i] = s_mask[i];
       pl.chunk[l][slot0 + i] = s_cnt[i];
     }
   } else {
-    for (int i = tid; i < nslots; i += CW_COLS * CW_LANES) {
+    for (int i = tid; i < nslots; i += CW_COLS * LANES) {
       s_mask[i] = pl.cmask[l][slot0 + i];
       s_cnt[i] = pl.chunk[l][slot0 + i];
     }
@@ -918,7 +922,7 @@ __global__ void __launch_bounds__(CW_COLS * CW_LANES) k_compact_walk(PyrGeom g, 
     const bool staged = total <= CW_STAGE;
     float4* out = pl.pts[l] + (size_t)f * lv.npix;
     if (x < lv.w) {
-      for (int c = cl; c < lv.nchunk; c += CW_LANES) {
+      for (int c = cl; c < lv.nchunk; c += LANES) {
         const int yb = c * lv.chunk_rows;
         int o = s_cnt[xl * lv.nchunk + c] - (staged ? base : 0);
         float4* dst = staged ? s_pts : out;
@@ -944,7 +948,7 @@ __global__ void __launch_bounds__(CW_COLS * CW_LANES) k_compact_walk(PyrGeom g, 
     }
     if (staged) {
       __syncthreads();
-      for (int i = tid; i < total; i += CW_COLS * CW_LANES) out[base + i] = s_pts[i];
+      for (int i = tid; i < total; i += CW_COLS * LANES) out[base + i] = s_pts[i];
     }
   }
 }
@@ -1295,7 +1299,7 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid(g.total_strips, 1, B);
-  hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
+  hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(CW_COLS * CW_LANES_COUNT), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
 }
