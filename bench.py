@@ -193,7 +193,7 @@ def main():
         counter[0] += 1
         if nbuf == 2:
             s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
-            bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=s_build.cuda_stream)
+            bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=s_build.cuda_stream, borrow_depth=True)
             ev_built[k].record(s_build)
             s_track.wait_event(ev_built[k])
             if timing[0]:  # HIP events around the tracker launch, on its stream, inside the timed region
@@ -205,7 +205,8 @@ def main():
             else:
                 bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
         else:
-            bts[k].track(d_bgr.data_ptr(), d_dep.data_ptr(), d_out.data_ptr(), stream=stream)
+            bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream, borrow_depth=True)
+            bts[k].track_only(d_out.data_ptr(), stream=stream)
         if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1)
             gathered[0] = parallel.gather_records(d_out, world, out=d_all)
         ev_tracked[k].record(s_track)

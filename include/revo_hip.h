@@ -277,6 +277,11 @@ int revo_batch_track(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
 /* Stage-wise variants used by bench.py for per-kernel timing. */
 int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
                      void* stream);
+/* revo_batch_build without the copy of the depth input: level 0 of the depth pyramid IS d_depth (the reference's
+ * level 0 is the input image as well, imgpyramidrgbd.cpp:62-64).  d_depth must stay valid and unchanged until the
+ * batch is built again or destroyed -- accessors, the tracker's point lists and the keyframe promotion read it. */
+int revo_batch_build_borrow(revo_batch* b, const uint8_t* d_bgr, const float* d_depth,
+                            void* stream);
 /* revo_batch_build for raw uint16 depth [2*n_pairs][H][W] (depth = raw * (float)(1/scale),
  * iowrapperRGBD.cpp:326-327, fused into the first build kernel). */
 int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const uint16_t* d_depth_raw,

@@ -91,6 +91,7 @@ def lib():
     L.revo_batch_destroy.restype = None
     L.revo_batch_track.argtypes = [vp, vp, vp, f32p, vp, vp]
     L.revo_batch_build.argtypes = [vp, vp, vp, vp]
+    L.revo_batch_build_borrow.argtypes = [vp, vp, vp, vp]
     L.revo_batch_build_u16.argtypes = [vp, vp, vp, C.c_double, vp]
     L.revo_batch_track_only.argtypes = [vp, f32p, vp, vp]
     L.revo_batch_sync.argtypes = [vp, vp]

@@ -334,8 +334,11 @@ class BatchTracker:
         keep, ptr = self._init(init_RT)
         check(_lib.lib().revo_batch_track(self._h, d_bgr, d_depth, ptr, d_results, stream))
 
-    def build(self, d_bgr, d_depth, stream=None):
-        check(_lib.lib().revo_batch_build(self._h, d_bgr, d_depth, stream))
+    def build(self, d_bgr, d_depth, stream=None, borrow_depth=False):
+        """borrow_depth: level 0 of the depth pyramid is d_depth itself (no copy); the caller keeps the buffer alive
+        and unchanged until the next build of this batch."""
+        fn = _lib.lib().revo_batch_build_borrow if borrow_depth else _lib.lib().revo_batch_build
+        check(fn(self._h, d_bgr, d_depth, stream))
 
     def build_u16(self, d_bgr, d_depth_raw, depth_scale_factor, stream=None):
         """build() for raw uint16 depth (device pointer); the metres conversion is fused into the build."""

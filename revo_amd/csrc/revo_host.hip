@@ -66,6 +66,7 @@ struct FrameSet {
   void* blob = nullptr;
   size_t blob_bytes = 0;
   FramePlanes p{};
+  float* own_depth0 = nullptr;  // the set's own level-0 depth plane (p.depth[0] may point at a borrowed input instead)
   uint8_t* d_bgr = nullptr;   // input staging (single-frame API)
   float* d_depth = nullptr;   // input staging; aliased as u16 for the u16 entry point
   // asynchronous creation (single-frame API): pinned host staging, "built" and "released" events
@@ -315,6 +316,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       fs->p.chunk[l] = (int*)take((size_t)v.w * v.nchunk * B * 4);
       fs->p.cmask[l] = (unsigned*)take((size_t)v.w * v.nchunk * B * 4);
     }
+    fs->own_depth0 = fs->p.depth[0];
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.hist_nz = (int*)take(sizeof(int) * REVO_L * B);
     if (with_staging) {
@@ -349,12 +351,16 @@ static void frameset_destroy(FrameSet* fs) {
   delete fs;
 }
 
-// enqueue the full per-frame build (imgpyramidrgbd.cpp:43-96) for all B frames
+// enqueue the full per-frame build (imgpyramidrgbd.cpp:43-96) for all B frames.
+// borrow_depth (f32 input only): the level-0 depth plane IS the input buffer -- the reference's level 0 is the input
+// image too (imgpyramidrgbd.cpp:62-64), and copying 64 x 1.2 MB per batch was 208 of the 236 MB the first kernel moved.
+// The caller guarantees the buffer stays valid and unchanged for as long as the pyramids are used.
 static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
-                          const uint16_t* d_depth_u16, float alpha, hipStream_t s, int f0 = 0, int count = -1) {
+                          const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false) {
   PyrGeom g = c->geom;
-  g.frame0 = f0;
-  const int B = count < 0 ? fs->B : count;
+  g.frame0 = 0;
+  const int B = fs->B;
+  fs->p.depth[0] = (borrow_depth && d_depth_f32) ? const_cast<float*>(d_depth_f32) : fs->own_depth0;
   launch_gray_depth(g, fs->p, d_bgr, d_depth_f32, d_depth_u16, alpha, B, s);
   for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, B, s);
   launch_canny_nms(g, fs->p, B, s);
@@ -498,7 +504,8 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   HIPCHECK(hipMemcpyAsync(fs->d_bgr, fs->h_bgr, brow * h, hipMemcpyHostToDevice, bs));
   HIPCHECK(hipMemcpyAsync(fs->d_depth, fs->h_depth, drow * h, hipMemcpyHostToDevice, bs));
   const float alpha = is_u16 ? (float)(1.0f / scale) : 0.0f;  // iowrapperRGBD.cpp:327
-  enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha, bs);
+  // (the f32 staging plane is the set's own memory: level 0 reads it in place)
+  enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha, bs, true);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_ready, bs));
   fs->has_ready = true;
@@ -998,20 +1005,26 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   ctx_unref(c);
 }
 
-extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream) {
+static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream, bool borrow) {
   if (!b || !d_bgr || !d_depth) return fail(REVO_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
   // (Splitting the batch into slices of pairs on 2 / 4 streams was measured in both rounds: no gain in round 1,
   // and with the round-2 kernels the step goes from 0.64 ms to 0.73 / 0.84 ms next to a tracker -- the build
   // kernels are throughput-limited, smaller launches only add tails.)
-  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s);
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow);
   launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;
   for (auto& v : b->views) v.table_built = false;
   return REVO_OK;
+}
+extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream) {
+  return batch_build_f32(b, d_bgr, d_depth, stream, false);
+}
+extern "C" int revo_batch_build_borrow(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream) {
+  return batch_build_f32(b, d_bgr, d_depth, stream, true);
 }
 
 static int batch_upload_init(revo_batch* b, const float* h_init_RT, hipStream_t s) {
@@ -1203,7 +1216,7 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   hipStream_t s = j->stream;
   HIPCHECK(hipStreamWaitEvent(s, j->ev_h2d, 0));
   int rc = depth_is_u16 ? revo_batch_build_u16(j->batch, j->d_bgr, (const uint16_t*)j->d_depth, depth_scale_factor, s)
-                        : revo_batch_build(j->batch, j->d_bgr, (const float*)j->d_depth, s);
+                        : revo_batch_build_borrow(j->batch, j->d_bgr, (const float*)j->d_depth, s);  // the job's own staging
   if (!rc) rc = revo_batch_track_only(j->batch, any_init ? j->h_init : nullptr, j->d_res, s);
   if (rc) { j->busy = false; return rc; }
   HIPCHECK(hipMemcpyAsync(j->h_res, j->d_res, sizeof(revo_pair_result) * n, hipMemcpyDeviceToHost, s));

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ 
   const uint32_t y2 = (uint32_t)(B2 * 1868 + G2 * 9617 + R2 * 4899 + 8192) >> 14;
   const uint32_t y3 = (uint32_t)(B3 * 1868 + G3 * 9617 + R3 * 4899 + 8192) >> 14;
   reinterpret_cast<uint32_t*>(gray + (size_t)f * npix)[g4] = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+  if (depth_out == depth_f32) return;  // level 0 borrows the input plane: nothing to copy
   float4 d;
   if (depth_u16) {
     const uint2 r = reinterpret_cast<const uint2*>(depth_u16 + (size_t)f * npix)[g4];

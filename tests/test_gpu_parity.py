@@ -452,6 +452,48 @@ def test_batch_u16_depth_matches_the_u16_single_frame_path(api, ro):
     assert res[0] == res[1]
 
 
+def test_batch_build_with_borrowed_depth_equals_the_copying_build(api, ro):
+    """revo_batch_build_borrow: level 0 of the depth pyramid is the caller's buffer (no copy).  Every plane, the
+    edge lists and the tracker records equal the copying build's, the level-0 accessor returns the input, and a
+    copying build afterwards goes back to the batch's own plane."""
+    import torch
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    n_pairs = 2
+    pairs = [synth.make_pair(60 + i, s) for i in range(n_pairs)]
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    bgr = np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])
+    dep = np.stack([p[k][1] for p in pairs for k in ("ref", "curr")]).astype(np.float32)
+    d_bgr, d_dep = torch.from_numpy(bgr).cuda(), torch.from_numpy(dep).cuda()
+    bt_copy, bt_borrow = api.BatchTracker(cam, n_pairs), api.BatchTracker(cam, n_pairs)
+    r_copy = torch.zeros(n_pairs * 96, dtype=torch.uint8, device="cuda")
+    r_borrow = torch.zeros(n_pairs * 96, dtype=torch.uint8, device="cuda")
+    bt_copy.build(d_bgr.data_ptr(), d_dep.data_ptr())
+    bt_borrow.build(d_bgr.data_ptr(), d_dep.data_ptr(), borrow_depth=True)
+    bt_copy.track_only(r_copy.data_ptr()); bt_borrow.track_only(r_borrow.data_ptr())
+    bt_copy.sync(); bt_borrow.sync()
+    assert r_copy.cpu().numpy().tobytes() == r_borrow.cpu().numpy().tobytes()
+    for f in range(2 * n_pairs):
+        a, b = bt_copy.frame(f, s), bt_borrow.frame(f, s)
+        for lvl in range(3):
+            assert_same("borrow_depth", b.returnDepth(lvl), a.returnDepth(lvl))
+            assert_same("borrow_pts", b.return3DEdges(lvl), a.return3DEdges(lvl))
+            assert_same("borrow_edges", b.returnEdges(lvl), a.returnEdges(lvl))
+        assert_same("borrow_is_input", b.returnDepth(0), dep[f])
+    # the borrowed plane is the caller's memory: changing it shows through; a copying build detaches again
+    d_dep2 = d_dep.clone()
+    bt_borrow.build(d_bgr.data_ptr(), d_dep2.data_ptr(), borrow_depth=True)
+    bt_borrow.sync()
+    d_dep2[0, 0, 0] = 123.0
+    torch.cuda.synchronize()
+    assert bt_borrow.frame(0, s).returnDepth(0)[0, 0] == np.float32(123.0)
+    bt_borrow.build(d_bgr.data_ptr(), d_dep.data_ptr())
+    bt_borrow.sync()
+    d_dep2[0, 0, 1] = 77.0
+    torch.cuda.synchronize()
+    assert_same("copy_again", bt_borrow.frame(0, s).returnDepth(0), dep[0])
+
+
 def test_many_pairs_pose_parity_statistics(api, ro):
     """48 seeded pairs through one batch vs the oracle pair by pair.  Two faithful implementations of this LM can
     stop at different points inside its 0.999 convergence slack when a decision is borderline, so the bar is
