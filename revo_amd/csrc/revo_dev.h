@@ -60,6 +60,7 @@ struct FramePlanes {
   unsigned* cmask[REVO_L];     // per (column, 32-row chunk): bit y = edge pixel with valid depth
   int* npts;                   // [B][REVO_L]
   int* hist_nz;                // [B][REVO_L]
+  int* strip_tot;              // [B][total_strips]: edge points per 64-column strip (the compaction's cross-strip offsets)
 };
 
 // One frame-pair for the tracker kernel.

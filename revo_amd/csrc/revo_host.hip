@@ -319,6 +319,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
     fs->own_depth0 = fs->p.depth[0];
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.hist_nz = (int*)take(sizeof(int) * REVO_L * B);
+    fs->p.strip_tot = (int*)take(sizeof(int) * (size_t)g.total_strips * B);
     if (with_staging) {
       fs->d_bgr = (uint8_t*)take((size_t)g.lv[0].npix * 3 * B);
       fs->d_depth = (float*)take((size_t)g.lv[0].npix * 4 * B);

@@ -840,8 +840,9 @@ __global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
 // is identical to the reference's, element for element.
 //   count : one thread per (column, 32-row chunk), adjacent threads = adjacent
 //           columns -> coalesced row reads
-//   scan  : one block per (frame, level), exclusive scan in column-major chunk order
-//   write : same walk, emits float4 (X,Y,Z,1) at the scanned offset
+//   write : same walk; offsets = the point counts of the level's earlier strips (one int per strip, left by the
+//           count pass) + an exclusive scan of the strip's own slot counts in LDS; emits float4 (X,Y,Z,1).
+//           (Round 1 ran a scan kernel per (frame, level) between the passes: 10 us alone, 28 us next to a tracker.)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
   return isfinite(Z) && Z > dmin && Z < dmax;  // imgpyramidrgbd.cpp:208
@@ -908,18 +909,62 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
       }
     }
     __syncthreads();
+    int mine = 0;
     for (int i = tid; i < nslots; i += CW_COLS * LANES) {
       pl.cmask[l][slot0 + i] = s_mask[i];
       pl.chunk[l][slot0 + i] = s_cnt[i];
+      mine += s_cnt[i];
     }
+    // the strip's point count: all the write pass needs from the other strips (no scan kernel in between)
+    __shared__ int s_tot;
+    if (tid == 0) s_tot = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((tid & 63) == 0 && mine) atomicAdd(&s_tot, mine);
+    __syncthreads();
+    if (tid == 0) pl.strip_tot[(size_t)f * g.total_strips + blockIdx.x] = s_tot;
   } else {
     for (int i = tid; i < nslots; i += CW_COLS * LANES) {
       s_mask[i] = pl.cmask[l][slot0 + i];
       s_cnt[i] = pl.chunk[l][slot0 + i];
     }
     __syncthreads();
-    const int base = s_cnt[0];
-    const int total = s_cnt[nslots - 1] + __popc(s_mask[nslots - 1]) - base;
+    // offsets: the points of the level's earlier strips + an exclusive scan of this strip's slot counts
+    // (slot order = list order: x-major, chunk-minor), in place in s_cnt
+    int* s_wsum = reinterpret_cast<int*>(s_pts);  // 16 wave totals in the (still unused) staging area: the block's LDS stays at
+                                                  // exactly 80 KB, two blocks per CU (64 more bytes halved the occupancy: 36 -> 55 us)
+    // (width <= 2048: at most 32 strips per level -- one load per lane and a butterfly, in every wave)
+    int base = (tid & 63) < strip ? pl.strip_tot[(size_t)f * g.total_strips + lv.strip_base + (tid & 63)] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    int total;
+    {
+      constexpr int NT = CW_COLS * CW_LANES;  // (the write pass; this branch is dead code in the count instantiation)
+      static_assert(CW_COLS * CW_MAXCHUNK <= 2 * NT, "two slots per thread");
+      const int i0 = 2 * tid, i1 = 2 * tid + 1;
+      const int c0 = i0 < nslots ? s_cnt[i0] : 0, c1 = i1 < nslots ? s_cnt[i1] : 0;
+      const int sum = c0 + c1;
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+      }
+      if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+      __syncthreads();
+      // wave totals: lane k holds wave k's, two butterflies give this wave's prefix and the strip total
+      const int wv = (tid & 63) < NT / 64 ? s_wsum[tid & 63] : 0;
+      int pre = (tid & 63) < (tid >> 6) ? wv : 0;
+      total = wv;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); total += __shfl_xor(total, o); }
+      const int run = base + pre + incl - sum;
+      if (i0 < nslots) s_cnt[i0] = run;
+      if (i1 < nslots) s_cnt[i1] = run + c0;
+      __syncthreads();
+    }
+    if (tid == 0 && strip == (lv.w + CW_COLS - 1) / CW_COLS - 1) pl.npts[f * REVO_L + l] = base + total;
     const bool staged = total <= CW_STAGE;
     float4* out = pl.pts[l] + (size_t)f * lv.npix;
     if (x < lv.w) {
@@ -954,34 +999,34 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
   }
 }
 
-// exclusive scan of a[0..n) by one 1024-thread block; returns the total (valid in every thread)
+// exclusive scan of a[0..n) by one 1024-thread block; returns the total (valid in every thread).  Per-thread
+// segments, a shuffle scan inside each wave and the 16 wave totals through LDS: two barriers (the Hillis-Steele
+// scan over 1024 LDS entries it replaces took twenty).  s_part: >= 16 ints.
 __device__ __forceinline__ int block_exclusive_scan(int* a, int n, int* s_part) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n + 1023) / 1024;
   const int b = min(n, tid * per), e = min(n, b + per);
   int sum = 0;
   for (int i = b; i < e; ++i) sum += a[i];
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    const int v = (tid >= off) ? s_part[tid - off] : 0;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
   }
-  int run = s_part[tid] - sum;  // exclusive prefix of this thread's segment
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  int run = incl - sum, total = 0;  // exclusive prefix of this thread's segment
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int wv = s_part[k];
+    run += k < wave ? wv : 0;
+    total += wv;
+  }
   for (int i = b; i < e; ++i) { const int c = a[i]; a[i] = run; run += c; }
-  return s_part[1023];
+  return total;
 }
 
-__global__ void __launch_bounds__(1024) k_compact_scan(PyrGeom g, FramePlanes pl) {
-  __shared__ int s_part[1024];
-  const int nB = gridDim.x / g.n_levels;  // level-major 1-D grid (see k_hyst: spreads the big level over all XCDs)
-  const int f = g.frame0 + blockIdx.x % nB, l = blockIdx.x / nB;
-  const int n = g.lv[l].w * g.lv[l].nchunk;
-  const int total = block_exclusive_scan(pl.chunk[l] + (size_t)f * n, n, s_part);
-  if (threadIdx.x == 0) pl.npts[f * REVO_L + l] = total;
-}
 
 // ---------------------------------------------------------------------------
 // generateColoredPcl (imgpyramidrgbd.cpp:279-327), the viewer / PLY-export cloud of a keyframe:
@@ -1301,7 +1346,6 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   dim3 grid(g.total_strips, 1, B);
   hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(CW_COLS * CW_LANES_COUNT), 0, s, g, p);
-  hipLaunchKernelGGL(k_compact_scan, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
 }
 
