@@ -144,6 +144,34 @@ def main():
         raise SystemExit("bench: rank %d needs GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from revo_amd import api, synth
+    cam = api.CameraPyr(s, device=local_rank)
+    api.TrackerNew(TrackerSettings(), s, cam)
+
+    # ---- side measurement, taken FIRST: ONE sequential stream through the host-buffer API (BASELINE configs[1]
+    # stand-in: no TUM data here).  Frame N depends on frame N-1, so this is latency-bound and PCIe-inclusive; it is
+    # reported next to, never as, `value`.  It runs before the process group exists because a sequential VO process
+    # has no collective, and an initialised RCCL communicator slows the latency-bound stream down for the rest of
+    # the process's life, destroyed or not (measured on the same box: 3.5 k frames/s before init, 2.35 k after).
+    seq_gpu = None
+    if rank == 0 and world == 1 and a.single_stream_frames > 0:
+        from revo_amd import vo
+        n_seq = a.single_stream_frames
+        # a seeded synthetic camera sweep (TUM-like inter-frame motion: ~4 mm, 1 deg per frame)
+        seq = synth.make_sequence(7, s, n_seq, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
+        stream_frames = [(f[0], f[1], f[2]) for f in seq]
+        vo.REVO(s, cameraPyr=cam).run(stream_frames[:6])  # warm-up (pools, first-touch)
+        runs = []
+        for _ in range(3):  # host-side jitter (threads, PCIe) is large for a 25 ms run: best of three, all reported
+            drv = vo.REVO(s, cameraPyr=cam)
+            t0 = time.perf_counter()
+            drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
+            runs.append(time.perf_counter() - t0)
+        rpe = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
+        seq_gpu = {"runs": runs, "keyframes": drv.nKeyFrames, "rpe": rpe,
+                   "ate": synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])}
+        del drv
+
     # The path's only collective runs through RCCL at every N, N = 1 included (the world-size-1
     # path is the single-GPU CI of the multi-GPU job).
     group_error = None
@@ -159,9 +187,6 @@ def main():
             group_error = "%s: %s" % (type(e).__name__, e)
     use_group = dist.is_initialized()
 
-    from revo_amd import api, synth
-    cam = api.CameraPyr(s, device=local_rank)
-    api.TrackerNew(TrackerSettings(), s, cam)
     # Two batches, two streams: the pyramid build of step k+1 (streaming, all CUs) overlaps the
     # tracker of step k (192 latency-bound workgroups).  Trackers serialise on one stream,
     # builds on the other; events hand each batch back and forth.
@@ -175,7 +200,8 @@ def main():
     d_res_all = torch.zeros(max(1, n_slots) * a.pairs * 96, dtype=torch.uint8, device=dev)
     d_ress = [d_res_all[i * a.pairs * 96:(i + 1) * a.pairs * 96] for i in range(max(1, n_slots))]
     d_res = d_ress[0]
-    s_track = torch.cuda.Stream(device=dev)   # also carries the RCCL collective
+    s_track = torch.cuda.Stream(device=dev)
+    s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev) if nbuf == 2 else s_track
     torch.cuda.set_stream(s_track)
     stream = s_track.cuda_stream
@@ -207,9 +233,13 @@ def main():
         else:
             bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream, borrow_depth=True)
             bts[k].track_only(d_out.data_ptr(), stream=stream)
-        if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1)
-            gathered[0] = parallel.gather_records(d_out, world, out=d_all)
         ev_tracked[k].record(s_track)
+        if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
+            # nothing on the device waits for it (the host reads the gathered records after the run), so it is off the
+            # tracker stream's chain; it is inside the timed region all the same (synchronize + barrier below)
+            s_coll.wait_event(ev_tracked[k])
+            with torch.cuda.stream(s_coll):
+                gathered[0] = parallel.gather_records(d_out, world, out=d_all)
 
     for _ in range(a.warmup):
         step()
@@ -273,7 +303,7 @@ def main():
     tb = tk = 0.0
     for _ in range(reps):
         e0.record()
-        bt.build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream)
+        bt.build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream, borrow_depth=True)
         e1.record()
         bt.track_only(d_res.data_ptr(), stream=stream)
         e2.record()
@@ -288,7 +318,8 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if os.path.exists(pmc_file) and a.pairs == 32 and a.width == 640 and a.levels == 4:
         try:
-            traffic = float(json.load(open(pmc_file))["k_track"]["hbm_bytes_per_launch"])
+            pmc = json.load(open(pmc_file))
+            traffic = float(next(v for k, v in pmc.items() if k.startswith("k_track"))["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
     # on-box streaming ceiling next to the vendor peak: a 1 GiB device-to-device copy
@@ -407,25 +438,13 @@ def main():
         out["host_buffers"] = hostb
         out["value_incl_h2d"] = hostb["u16"]["value_incl_h2d"]
 
-    # ---- side measurement: ONE sequential stream through the host-buffer API (BASELINE configs[1]
-    # stand-in: no TUM data here).  Frame N depends on frame N-1, so this is latency-bound and
-    # PCIe-inclusive; it is reported next to, never as, `value`.
-    if rank == 0 and world == 1 and a.single_stream_frames > 0:
-        from revo_amd import vo
-        n = a.single_stream_frames
-        # a seeded synthetic camera sweep (TUM-like inter-frame motion: ~4 mm, 1 deg per frame)
-        seq = synth.make_sequence(7, s, n, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
-        stream_frames = [(f[0], f[1], f[2]) for f in seq]
-        vo.REVO(s, cameraPyr=cam).run(stream_frames[:6])  # warm-up (pools, first-touch)
-        runs = []
-        for _ in range(3):  # host-side jitter (threads, PCIe) is large for a 25 ms run: best of three, all reported
-            drv = vo.REVO(s, cameraPyr=cam)
-            t0 = time.perf_counter()
-            drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
-            runs.append(time.perf_counter() - t0)
-        dt_seq = min(runs)
-        ate_seq = synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
-        rpe_t, rpe_r = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
+    # ---- the sequential stream measured at the start: its CPU counterpart and the record
+    if seq_gpu is not None:
+        n = n_seq
+        dt_seq = min(seq_gpu["runs"])
+        runs = seq_gpu["runs"]
+        ate_seq = seq_gpu["ate"]
+        rpe_t, rpe_r = seq_gpu["rpe"]
         cpu_seq = cpu_seq_2core = cpu_trk_only = None
         seq_pinned, seq_passes = None, 0
         if a.cpu_baseline != "off":  # the same stream through the oracle's REVO::start restatement
@@ -451,7 +470,7 @@ def main():
             seq_passes = len(times_seq) - 1
             cpu_seq_2core = nseq / float(np.median(times_seq[1:]))
         out["single_stream"] = {"frames_per_s": n / dt_seq, "frames_per_s_runs": [n / t for t in runs], "frames": n,
-                                "keyframes": drv.nKeyFrames,
+                                "keyframes": seq_gpu["keyframes"],
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
                                 "rpe_rmse_per_frame": {"trans_m": rpe_t, "rot_rad": rpe_r},
                                 "cpu_oracle_frames_per_s_1core": cpu_seq,

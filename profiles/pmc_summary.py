@@ -1,7 +1,8 @@
 """Builds profiles/rNN_pmc_summary.json from two rocprofv3 --pmc rocpd databases (FETCH_SIZE pass, WRITE_SIZE pass):
 HBM bytes per launch per kernel, FETCH_SIZE doubled (gfx950: 128-B requests tallied as 64 B,
 MI355X_MICROARCH.md "HBM") and calibrated on k_gray_depth, whose bytes are known.
-usage: pmc_summary.py <fetch.db> <write.db> <pairs> <width> <height> <command string> > summary.json"""
+usage: pmc_summary.py <fetch.db> <write.db> <pairs> <width> <height> <command string> [borrow] > summary.json
+(borrow: the build borrowed the f32 depth input, so k_gray_depth only reads BGR and writes gray)"""
 import collections
 import json
 import sqlite3
@@ -30,6 +31,7 @@ for k in sorted(set(fetch) | set(write)):
     f, wr = fetch.get(k, 0.0), write.get(k, 0.0)
     out[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": wr, "hbm_bytes_per_launch": (2 * f + wr) * 1024.0}
 npix = w * h
-out["calibration_k_gray_depth"] = {"known_read_KB": 2 * pairs * npix * 7 / 1024.0, "known_write_KB": 2 * pairs * npix * 5 / 1024.0,
+rb, wb = (3, 1) if len(sys.argv) > 7 and sys.argv[7] == "borrow" else (7, 5)
+out["calibration_k_gray_depth"] = {"known_read_KB": 2 * pairs * npix * rb / 1024.0, "known_write_KB": 2 * pairs * npix * wb / 1024.0,
                                    "FETCH_SIZE_KB": fetch.get("k_gray_depth"), "WRITE_SIZE_KB": write.get("k_gray_depth")}
 print(json.dumps(out, indent=1))
