@@ -58,6 +58,8 @@ struct FramePlanes {
   uint8_t* hist[REVO_L];       // histPyr (frame stride hist_w*hist_h)
   int* chunk[REVO_L];          // compaction counts -> offsets (frame stride w*nchunk)
   unsigned* cmask[REVO_L];     // per (column, 32-row chunk): bit y = edge pixel with valid depth
+  uint8_t* vb[REVO_L];         // depth validity, one bit per pixel (byte = 8 pixels of a row), written by the pyrDown that
+                               // reads the level anyway; the coarsest level has none (frame stride npix/8)
   int* npts;                   // [B][REVO_L]
   int* hist_nz;                // [B][REVO_L]
   int* strip_tot;              // [B][total_strips]: edge points per 64-column strip (the compaction's cross-strip offsets)

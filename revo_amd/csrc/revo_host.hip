@@ -315,6 +315,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       fs->p.hist[l] = (uint8_t*)take((size_t)std::max(1, v.hist_w * v.hist_h) * B);
       fs->p.chunk[l] = (int*)take((size_t)v.w * v.nchunk * B * 4);
       fs->p.cmask[l] = (unsigned*)take((size_t)v.w * v.nchunk * B * 4);
+      fs->p.vb[l] = (uint8_t*)take((n + 7) / 8);
     }
     fs->own_depth0 = fs->p.depth[0];
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);

@@ -89,12 +89,14 @@ __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ 
 // Separable [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8.  Source width is a multiple of 8.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
-                                                 int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst, int frame0) {
+                                                 int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst, int frame0,
+                                                 uint8_t* __restrict__ vsrc, float dmin, float dmax) {
   const int f = frame0 + blockIdx.z;
   src += (size_t)f * sw * sh;
   dst += (size_t)f * dw * dh;
   dsrc += (size_t)f * sw * sh;
   ddst += (size_t)f * dw * dh;
+  vsrc += (size_t)f * (sw >> 3) * sh;
   const int gw = dw >> 2, gh = (dh + 1) >> 1;  // groups of 4 outputs per row, pairs of output rows
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= gw * gh) return;
@@ -143,6 +145,17 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
     const float4 c0 = *reinterpret_cast<const float4*>(d0 + sw), c1 = *reinterpret_cast<const float4*>(d0 + sw + 4);
     const float top[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
     const float bot[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    // by-product: the SOURCE level's depth-validity bits (imgpyramidrgbd.cpp:208) -- this kernel reads every depth of
+    // that level anyway, and the edge-list count pass then needs no depth reads at all (they were sparse gathers
+    // that pulled the whole plane through HBM: 150 MB per launch for 41 MB of algorithmic bytes)
+    unsigned vt = 0, vbm = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      vt |= (isfinite(top[k]) && top[k] > dmin && top[k] < dmax) ? 1u << k : 0u;
+      vbm |= (isfinite(bot[k]) && bot[k] > dmin && bot[k] < dmax) ? 1u << k : 0u;
+    }
+    vsrc[(size_t)(2 * (oy + q)) * (sw >> 3) + gx] = (uint8_t)vt;
+    vsrc[(size_t)(2 * (oy + q) + 1) * (sw >> 3) + gx] = (uint8_t)vbm;
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -901,9 +914,18 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
         unsigned em = 0;
 #pragma unroll 8
         for (int y = yb; y < ye; ++y) em |= (edges[(size_t)y * lv.w + x] ? 1u : 0u) << (y - yb);
-        // four set bits per trip: the depth loads of a trip are independent, so a column with k edge
-        // pixels costs ceil(k/4) memory round trips instead of k
         unsigned vm = 0;
+        if (l < g.n_levels - 1) {  // depth validity comes as bits from the pyrDown that read this level
+          const uint8_t* vb = pl.vb[l] + (size_t)f * (lv.npix >> 3);
+          const int vpitch = lv.w >> 3;
+          if (em) {
+#pragma unroll 8
+            for (int y = yb; y < ye; ++y) vm |= ((unsigned)(vb[(size_t)y * vpitch + (x >> 3)] >> (x & 7)) & 1u) << (y - yb);
+            vm &= em;
+          }
+        } else
+        // the coarsest level: four set bits per trip -- the depth loads of a trip are independent, so a column with k
+        // edge pixels costs ceil(k/4) memory round trips instead of k
         for (unsigned m = em; m;) {
           int b[4];
           float Z[4];
@@ -1323,7 +1345,7 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
   const LevelGeom& sl = g.lv[lvl - 1];
   dim3 grid(((d.w / 4) * ((d.h + 1) / 2) + 255) / 256, 1, B);
   hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h,
-                     p.depth[lvl - 1], p.depth[lvl], g.frame0);
+                     p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max);
 }
 
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
