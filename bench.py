@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="frame-pairs per GPU per step")
+    ap.add_argument("--buffers", type=int, default=2, help="batches in rotation (2 = double-buffered: build k+1 overlaps tracker k)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
@@ -190,7 +191,7 @@ def main():
     # Two batches, two streams: the pyramid build of step k+1 (streaming, all CUs) overlaps the
     # tracker of step k (192 latency-bound workgroups).  Trackers serialise on one stream,
     # builds on the other; events hand each batch back and forth.
-    nbuf = 1 if a.no_overlap else 2
+    nbuf = 1 if a.no_overlap else max(2, a.buffers)
     bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf)]
     bt = bts[0]
     d_bgr = torch.from_numpy(bgr).to(dev)
@@ -202,13 +203,16 @@ def main():
     d_res = d_ress[0]
     s_track = torch.cuda.Stream(device=dev)
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
-    s_build = torch.cuda.Stream(device=dev) if nbuf == 2 else s_track
+    s_build = torch.cuda.Stream(device=dev) if nbuf >= 2 else s_track
     torch.cuda.set_stream(s_track)
     stream = s_track.cuda_stream
     assert stream != 0 and s_build.cuda_stream != 0
     ev_built = [torch.cuda.Event() for _ in range(nbuf)]
     ev_tracked = [torch.cuda.Event() for _ in range(nbuf)]
     counter = [0]
+    # the timing events cost ~1.5 % of the step when every launch carries a pair (two marker packets in front of / behind
+    # each tracker on its stream): every 4th launch of the timed region is timed (every launch when there are few)
+    TIME_EVERY = int(os.environ.get('REVO_BENCH_TIME_EVERY', '4' if a.steps >= 16 else '1'))
     timing, track_events = [False], []  # the dominant kernel is timed live in the timed steps (roofline)
     gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
     d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if use_group else None
@@ -217,12 +221,12 @@ def main():
         k = counter[0] % nbuf
         d_out = d_ress[counter[0] % len(d_ress)]
         counter[0] += 1
-        if nbuf == 2:
+        if nbuf >= 2:
             s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
             bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=s_build.cuda_stream, borrow_depth=True)
             ev_built[k].record(s_build)
             s_track.wait_event(ev_built[k])
-            if timing[0]:  # HIP events around the tracker launch, on its stream, inside the timed region
+            if timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
                 e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e_a.record(s_track)
                 bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
@@ -377,7 +381,7 @@ def main():
             "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of the default double-buffered command, this round's kernels)" if traffic else None,
             "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track, "kernel_ms_alone": ms_track_alone,
             "frac_alone": b_trk / (ms_track_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "timing": "HIP events on the tracker's stream around each of the %d timed launches" % max(1, len(track_events)),
+            "timing": "HIP events on the tracker's stream around %d of the %d launches of the timed region (every %d-th)" % (max(1, len(track_events)), a.steps, TIME_EVERY),
             "measured_copy_gbs": copy_gbs,  # on-box device-to-device copy ceiling (read + write bytes), for context
         },
         "collective": {"backend": "nccl (RCCL)" if use_group else None, "executed_every_step": bool(use_group),
