@@ -71,6 +71,68 @@ def render_pair(args):
     return p["ref"][0], p["ref"][1], p["curr"][0], p["curr"][1], p["T_ref_curr"]
 
 
+def nearest_positions(gt, stamps, max_dt=0.02):
+    """ground-truth positions at the estimate's time stamps (nearest within max_dt seconds, like TUM's associate.py)"""
+    keys = np.array(sorted(gt))
+    out = []
+    for ts in stamps:
+        j = int(np.searchsorted(keys, ts))
+        best = min((k for k in (j - 1, j) if 0 <= k < len(keys)), key=lambda k: abs(keys[k] - ts), default=None)
+        out.append(gt[keys[best]] if best is not None and abs(keys[best] - ts) <= max_dt else None)
+    return out
+
+
+def run_tum_stream(a, device):
+    """The sequential stream on a TUM-layout folder: frames/s (PNG decode excluded: frames are decoded first, like the
+    synthetic sweep), keyframes, ATE vs groundtruth.txt when present, and -- unless --cpu-baseline off -- the oracle on
+    the first frames of the same input: trajectory difference GPU vs oracle (the 'ATE within 1 mm of the reference
+    trajectory on identical inputs' check of BASELINE configs[0])."""
+    from revo_amd import api, synth, tum, vo
+    from revo_amd.settings import ImgPyramidSettings
+    if not os.path.exists(os.path.join(a.tum_dir, "associate.txt")):
+        return {"error": "no associate.txt in %s" % a.tum_dir}
+    s3 = ImgPyramidSettings()  # config/dataset_tum1.yaml: fr1 intrinsics, 3 levels
+    frames = list(tum.frames(a.tum_dir, read_n_images=(a.tum_frames - 1) if a.tum_frames > 0 else None))
+    if len(frames) < 3 or frames[0][0].shape[:2] != (s3.height, s3.width):
+        return {"error": "need >= 3 frames of %dx%d" % (s3.width, s3.height)}
+    cam = api.CameraPyr(s3, device=device)
+    vo.REVO(s3, cameraPyr=cam, depth_scale_factor=5000.0).run(frames[:6])
+    runs = []
+    for _ in range(3):
+        drv = vo.REVO(s3, cameraPyr=cam, depth_scale_factor=5000.0)
+        t0 = time.perf_counter()
+        drv.run(frames)
+        runs.append(time.perf_counter() - t0)
+    out = {"folder": os.path.basename(os.path.normpath(a.tum_dir)), "frames": len(frames), "levels": 3,
+           "frames_per_s": len(frames) / min(runs), "frames_per_s_runs": [len(frames) / t for t in runs],
+           "keyframes": drv.nKeyFrames, "note": "decoded frames in host memory -> revo_vo_* (H2D + build on the IO thread)"}
+    gt_file = os.path.join(a.tum_dir, "groundtruth.txt")
+    if os.path.exists(gt_file):
+        gt = tum.read_groundtruth_positions(gt_file)
+        ref = nearest_positions(gt, [ts for ts, _ in drv.poses])
+        est = [M for (ts, M), g in zip(drv.poses, ref) if g is not None]
+        refm = []
+        for g in ref:
+            if g is not None:
+                G = np.eye(4)
+                G[:3, 3] = g
+                refm.append(G)
+        if len(est) > 2:
+            out["ate_rmse_vs_groundtruth_m"] = synth.ate_rmse(est, refm)
+            out["ate_poses"] = len(est)
+    if a.cpu_baseline != "off":
+        from oracle import ro
+        n = min(len(frames), 40)
+        ovo = ro.VO(s3)
+        t0 = time.perf_counter()
+        o_poses = [ovo.push(bgr, ro.u16_to_depth(raw, 5000.0), ts)[0] for bgr, raw, ts in frames[:n]]
+        out["cpu_oracle_frames_per_s_1core"] = n / (time.perf_counter() - t0)
+        out["trajectory_rmse_gpu_vs_oracle_m"] = synth.ate_rmse([M for _, M in drv.poses[:n]], o_poses)
+        out["oracle_frames"] = n
+    del drv
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +150,11 @@ def main():
     ap.add_argument("--render-procs", type=int, default=0, help="0 = auto")
     ap.add_argument("--no-overlap", action="store_true", help="single batch, single stream (no build/track overlap)")
     ap.add_argument("--single-stream-frames", type=int, default=60, help="0 = skip the sequential-VO side measurement")
+    ap.add_argument("--tum-dir", default=os.environ.get("REVO_TUM_DIR", ""),
+                    help="a TUM-layout sequence folder (rgb/, depth/, associate.txt[, groundtruth.txt]), e.g. "
+                         "rgbd_dataset_freiburg1_desk: BASELINE configs[0]/[1] -- the sequential stream is then ALSO run "
+                         "on it (shipped 3-level settings, raw u16 depth / 5000) and reported as `tum_stream`")
+    ap.add_argument("--tum-frames", type=int, default=200, help="frames of --tum-dir to run (0 = all)")
     ap.add_argument("--skip-host-buffers", action="store_true", help="skip the host-buffer (H2D-inclusive) side measurement")
     ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the world-size-1 RCCL group")
     a = ap.parse_args()
@@ -172,6 +239,12 @@ def main():
         seq_gpu = {"runs": runs, "keyframes": drv.nKeyFrames, "rpe": rpe,
                    "ate": synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])}
         del drv
+
+    # ---- BASELINE configs[0]/[1]: a TUM sequence, when one is on disk (none ships with this repo).  Same driver, the
+    # shipped settings (640x480, 3 levels, config/dataset_tum1.yaml), raw 16-bit depth converted inside the build.
+    tum_out = None
+    if rank == 0 and world == 1 and a.tum_dir:
+        tum_out = run_tum_stream(a, local_rank)
 
     # The path's only collective runs through RCCL at every N, N = 1 included (the world-size-1
     # path is the single-GPU CI of the multi-GPU job).
@@ -394,6 +467,9 @@ def main():
         "evals_raw_mean": [float(x) for x in np.array([r["evals"] for r in res], np.float64).mean(0)],
         "input_render_s": t_render,
     }
+
+    if tum_out is not None:
+        out["tum_stream"] = tum_out
 
     # the collective has done its job (and been timed): RCCL's proxy threads must not compete with the host-side
     # measurements below (IO thread + consumer thread of the sequential stream) for the cgroup's CPUs

@@ -1,6 +1,8 @@
 """Sequential VO (REVO::start sequencing, system.cpp:84-305): product driver over the HIP path vs
 the oracle's restatement on the same synthetic sequence.  North-star bar: ATE of the HIP
 trajectory within 1 mm of the reference (= oracle) trajectory."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,3 +109,29 @@ def test_run_tum_cli_on_a_synthetic_tum_dataset(tmp_path, monkeypatch):
     print("ATE vs GT: HIP %.4f m, oracle %.4f m; trajectory vs trajectory %.4f m" % (ate_g, ate_o, synth.ate_rmse(est, ref)))
     assert abs(ate_g - ate_o) < 1e-3 and ate_g < 0.01
     assert synth.ate_rmse(est, ref) < 5e-3
+
+
+def test_bench_runs_a_tum_layout_folder(tmp_path):
+    """bench.py --tum-dir (BASELINE configs[0]/[1]: no TUM data ships, so a TUM-layout folder is written from the
+    seeded synthetic sweep): the line carries `tum_stream` with frames/s, keyframes, ATE vs groundtruth.txt and the
+    GPU-vs-oracle trajectory difference on identical inputs (bar: 1 mm)."""
+    import json
+    import subprocess
+    import sys
+    from revo_amd import synth, tum
+    from revo_amd.settings import ImgPyramidSettings
+    s3 = ImgPyramidSettings()
+    seq = synth.make_sequence(11, s3, 12, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
+    tum.write_synthetic_dataset(str(tmp_path), seq)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tum-dir", str(tmp_path), "--steps", "2", "--warmup", "1",
+                        "--pairs", "4", "--no-collective", "--skip-host-buffers", "--single-stream-frames", "0", "--render-procs", "1",
+                        "--cpu-baseline", "auto", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    t = json.loads(lines[0])["tum_stream"]
+    assert t["frames"] == 12 and t["frames_per_s"] > 0 and t["keyframes"] >= 1
+    assert t["ate_rmse_vs_groundtruth_m"] < 5e-3
+    assert t["trajectory_rmse_gpu_vs_oracle_m"] < 1e-3
