@@ -43,6 +43,7 @@
 //
 // There is no dense contraction here (a 6-vector outer product per point), so no MFMA.
 #include "revo_dev.h"
+#include "revo_div.h"
 
 namespace {
 
@@ -428,7 +429,7 @@ __device__ __forceinline__ DtPatch load_patch(gf32p dt, int w, int ix, int iy) {
   return q;
 }
 
-struct PtState { float X, Y, Z, dx, dy; int ix, iy; bool valid; };
+struct PtState { float X, Y, Z, rz, dx, dy; int ix, iy; bool valid; };  // rz: refined 1/Z (revo_div.h)
 struct Cam { float fx, fy, cx, cy, wlim, hlim; int w, h; };
 
 __device__ __forceinline__ PtState project_point(const f4v p, const float* R, const float* T, const Cam& c, bool in_range) {
@@ -436,14 +437,16 @@ __device__ __forceinline__ PtState project_point(const f4v p, const float* R, co
   s.X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
   s.Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
   s.Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
-  const float u = __fdiv_rn(s.X, s.Z) * c.fx + c.cx;
-  const float v = __fdiv_rn(s.Y, s.Z) * c.fy + c.cy;
+  // X/Z and Y/Z, correctly rounded, off ONE refined reciprocal (revo_div.h: the same bits as two IEEE divisions)
+  s.rz = revo_recip_refined(s.Z);
+  const float u = revo_div_with(s.X, s.Z, s.rz) * c.fx + c.cx;
+  const float v = revo_div_with(s.Y, s.Z, s.rz) * c.fy + c.cy;
   s.valid = in_range && (u > 1.0f && v > 1.0f && u < c.wlim && v < c.hlim);  // optimizer.cpp:100 (NaN-safe form)
   s.ix = s.valid ? (int)u : 1;
   s.iy = s.valid ? (int)v : 1;
   s.dx = u - (float)s.ix;
   s.dy = v - (float)s.iy;
-  if (!s.valid) { s.X = 0.0f; s.Y = 0.0f; s.Z = 1.0f; s.dx = 0.0f; s.dy = 0.0f; }
+  if (!s.valid) { s.X = 0.0f; s.Y = 0.0f; s.Z = 1.0f; s.rz = 1.0f; s.dx = 0.0f; s.dy = 0.0f; }
   return s;
 }
 
@@ -472,9 +475,9 @@ __device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch
   float res = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
   const bool good = s.valid && !(res > ed && filt);  // optimizer.cpp:108
   if (!good) { r0 = 0.0f; r1 = 0.0f; res = 0.0f; }
-  const float wr = (res <= huber) ? 1.0f : __fdiv_rn(huber, res);
+  const float wr = (res <= huber) ? 1.0f : revo_div(huber, res);
   const float gx = fx * r0, gy = fy * r1;
-  const float z = __fdiv_rn(1.0f, s.Z);
+  const float z = revo_div_with(1.0f, s.Z, s.rz);
   const float zs = z * z;  // reference: 1/(pz*pz), optimizer.cpp:213; differs by <= 1 ulp
   float jv[6];
   jv[0] = z * gx;
@@ -511,8 +514,9 @@ __device__ __forceinline__ float cost_point(const f4v p, gf32p dtm, const float*
   const float X = ((R[0] * p.x + R[3] * p.y) + R[6] * p.z) + T[0];
   const float Y = ((R[1] * p.x + R[4] * p.y) + R[7] * p.z) + T[1];
   const float Z = ((R[2] * p.x + R[5] * p.y) + R[8] * p.z) + T[2];
-  const float u = __fdiv_rn(c.fx * X, Z) + c.cx;
-  const float v = __fdiv_rn(c.fy * Y, Z) + c.cy;
+  const float rz = revo_recip_refined(Z);
+  const float u = revo_div_with(c.fx * X, Z, rz) + c.cx;
+  const float v = revo_div_with(c.fy * Y, Z, rz) + c.cy;
   float cost = 0.0f;
   if (u >= 0 && u < (float)c.w && v >= 0 && v < (float)c.h) {
     const float r = dtm[(int)floorf(v) * c.w + (int)floorf(u)];
@@ -560,7 +564,7 @@ __device__ __forceinline__ void error_points(const f4v p, gf32p dtm, const float
     float res = ((w11 * d11[j] + w01 * d01[j]) + w10 * d10[j]) + w00 * d00[j];
     const bool good = s[j].valid && !(res > ed && filt);
     if (!good) res = 0.0f;
-    const float wr = (res <= huber) ? 1.0f : __fdiv_rn(huber, res);
+    const float wr = (res <= huber) ? 1.0f : revo_div(huber, res);
     accumulate_error(res, wr, good, e + 3 * j);
   }
 }
