@@ -792,6 +792,11 @@ __global__ void __launch_bounds__(HYST_THREADS) HYST_OCC k_hyst(PyrGeom g, Frame
     *reinterpret_cast<uint4*>(edges + p) = v;
     if (orig) *reinterpret_cast<uint4*>(orig + p) = v;
   }
+  // the edge bitmap itself replaces the strong words (cs[].y): the edge-list count pass reads 32 pixels per load from it
+  {
+    uint2* csw = pl.cs[l] + (size_t)f * h * wpr;
+    for (int i = tid; i < nwords; i += HYST_THREADS) csw[i].y = E[pitch + i];
+  }
   HP(6);
   // histPyr[l] and the number of non-empty tiles (imgpyramidrgbd.cpp:146-172)
   if (lv.patch > 0) {
@@ -853,8 +858,11 @@ __global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
         const int yy = 2 * y + 1, xx = 2 * x + 1;
         const int ty = yy / lf.patch, tx = xx / lf.patch;
         if (ty >= lv.hist_h || tx >= lv.hist_w) continue;
-        if ((double)hist[(size_t)ty * lv.hist_w + tx] < thr && top[(size_t)yy * lf.w + xx] > 0)
+        if ((double)hist[(size_t)ty * lv.hist_w + tx] < thr && top[(size_t)yy * lf.w + xx] > 0) {
           mod[(size_t)y * lv.w + x] = 255;
+          // ... and in the level's edge bitmap (k_hyst left it in cs[].y), which the edge-list count pass reads
+          atomicOr(&(pl.cs[l] + (size_t)f * lv.h * lv.wpr)[(size_t)y * lv.wpr + (x >> 5)].y, 1u << (x & 31));
+        }
       }
     }
     __syncthreads();
@@ -908,6 +916,32 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
     // count: the depth plane is only touched where there is an edge (~8 % of the pixels); the
     // validity of the 32 rows is kept as a bit mask for the write pass
     const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
+    // Levels with depth-validity bits and whole 32-pixel words per row (the edge bitmap is k_hyst's, k_fill adds its
+    // pixels to it): edge AND validity as 32 x 32 bit tiles -- lane r of a half-wave loads the two words of row r (coalesced),
+    // five exchange steps transpose the tile, lane c ends with the row mask of column c.  Two loads per (column, chunk)
+    // instead of 64 byte loads.
+    const bool bit_tiles = l < g.n_levels - 1 && (lv.w & 31) == 0 && lv.chunk_rows == 32;
+    if (bit_tiles) {
+      const uint2* csw = pl.cs[l] + (size_t)f * lv.h * lv.wpr;
+      const uint32_t* vw = reinterpret_cast<const uint32_t*>(pl.vb[l] + (size_t)f * (lv.npix >> 3));
+      const int lane = tid & 63, r = lane & 31;
+      const int wc = strip * (CW_COLS / 32) + (lane >> 5);  // this half-wave's word column
+      for (int c = cl; c < lv.nchunk; c += LANES) {         // (wave-uniform)
+        const int y = c * 32 + r;
+        uint32_t v = 0;
+        if (y < lv.h && wc < lv.wpr) v = csw[(size_t)y * lv.wpr + wc].y & vw[(size_t)y * lv.wpr + wc];
+#pragma unroll
+        for (int k = 16; k >= 1; k >>= 1) {
+          const uint32_t mk = k == 16 ? 0x0000ffffu : k == 8 ? 0x00ff00ffu : k == 4 ? 0x0f0f0f0fu : k == 2 ? 0x33333333u : 0x55555555u;
+          const uint32_t t = (uint32_t)__shfl_xor((int)v, k);
+          v = (r & k) ? ((v & ~mk) | ((t >> k) & mk)) : ((v & mk) | ((t & mk) << k));
+        }
+        if (x < lv.w) {
+          s_mask[xl * lv.nchunk + c] = v;   // lane = column, bit = row of the chunk
+          s_cnt[xl * lv.nchunk + c] = __popc(v);
+        }
+      }
+    } else
     if (x < lv.w) {
       for (int c = cl; c < lv.nchunk; c += LANES) {
         const int yb = c * lv.chunk_rows, ye = min(lv.h, yb + lv.chunk_rows);
