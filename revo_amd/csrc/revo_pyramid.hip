@@ -879,6 +879,18 @@ __global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
 //           count pass) + an exclusive scan of the strip's own slot counts in LDS; emits float4 (X,Y,Z,1).
 //           (Round 1 ran a scan kernel per (frame, level) between the passes: 10 us alone, 28 us next to a tracker.)
 // ---------------------------------------------------------------------------
+// 32 x 32 bit tile held one row per lane (lane r of a 32-lane half-wave: bit c = pixel (r, c)) -> one column per lane
+// (lane c: bit r): the recursive block swap, five exchanges with lane ^ k
+__device__ __forceinline__ uint32_t tile_transpose32(uint32_t v, int r) {
+#pragma unroll
+  for (int k = 16; k >= 1; k >>= 1) {
+    const uint32_t mk = k == 16 ? 0x0000ffffu : k == 8 ? 0x00ff00ffu : k == 4 ? 0x0f0f0f0fu : k == 2 ? 0x33333333u : 0x55555555u;
+    const uint32_t t = (uint32_t)__shfl_xor((int)v, k);
+    v = (r & k) ? ((v & ~mk) | ((t >> k) & mk)) : ((v & mk) | ((t & mk) << k));
+  }
+  return v;
+}
+
 __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
   return isfinite(Z) && Z > dmin && Z < dmax;  // imgpyramidrgbd.cpp:208
 }
@@ -930,12 +942,7 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
         const int y = c * 32 + r;
         uint32_t v = 0;
         if (y < lv.h && wc < lv.wpr) v = csw[(size_t)y * lv.wpr + wc].y & vw[(size_t)y * lv.wpr + wc];
-#pragma unroll
-        for (int k = 16; k >= 1; k >>= 1) {
-          const uint32_t mk = k == 16 ? 0x0000ffffu : k == 8 ? 0x00ff00ffu : k == 4 ? 0x0f0f0f0fu : k == 2 ? 0x33333333u : 0x55555555u;
-          const uint32_t t = (uint32_t)__shfl_xor((int)v, k);
-          v = (r & k) ? ((v & ~mk) | ((t >> k) & mk)) : ((v & mk) | ((t & mk) << k));
-        }
+        v = tile_transpose32(v, r);
         if (x < lv.w) {
           s_mask[xl * lv.nchunk + c] = v;   // lane = column, bit = row of the chunk
           s_cnt[xl * lv.nchunk + c] = __popc(v);
@@ -1205,7 +1212,17 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
   const bool in = x < lv.w;
   const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
   unsigned em = 0;
-  if (in) {
+  if ((lv.w & 31) == 0 && (ncols & 31) == 0) {
+    // the level's edge bitmap (k_hyst / k_fill left it in cs[].y) as 32 x 32 bit tiles: lane r of a half-wave loads
+    // the word of row yb + r, the transpose hands every column its rows -- one load instead of 32 byte loads
+    const uint2* csw = pl.cs[l] + (size_t)f * lv.h * lv.wpr;
+    const int r = threadIdx.x & 31;
+    const int wc = (sidx * ncols + (col & ~31)) >> 5;
+    uint32_t v = 0;
+    if (yb + r < ye && wc < lv.wpr) v = csw[(size_t)(yb + r) * lv.wpr + wc].y;
+    em = tile_transpose32(v, r);
+    if (!in) em = 0;
+  } else if (in) {
 #pragma unroll 8
     for (int y = yb; y < ye; ++y) em |= (edges[(size_t)y * lv.w + x] ? 1u : 0u) << (y - yb);
   }
