@@ -914,10 +914,15 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
   __shared__ int s_cnt[CW_COLS * CW_MAXCHUNK];        // count pass: counts; write pass: offsets
   __shared__ unsigned s_mask[CW_COLS * CW_MAXCHUNK];
   __shared__ float4 s_pts[WRITE ? CW_STAGE : 1];
-  const int f = g.frame0 + blockIdx.z;
-  const int l = level_of(g, blockIdx.x, &LevelGeom::strip_base);
+  // 1-D grid, frame fastest: all strips of a frame get ids that are congruent mod 8 (batches are multiples of 8 frames
+  // wide in practice), i.e. land on ONE XCD and share its L2 -- they read the same lines of the frame's bitmaps, and
+  // with (strip, frame) = (x, z) every line was fetched into up to eight L2s
+  const int nB = gridDim.x / g.total_strips;
+  const int sx = blockIdx.x / nB;
+  const int f = g.frame0 + blockIdx.x % nB;
+  const int l = level_of(g, sx, &LevelGeom::strip_base);
   const LevelGeom& lv = g.lv[l];
-  const int strip = blockIdx.x - lv.strip_base;
+  const int strip = sx - lv.strip_base;
   const int tid = threadIdx.x, xl = tid & (CW_COLS - 1), cl = tid / CW_COLS;
   const int x = strip * CW_COLS + xl;
   const int ncols = min(CW_COLS, lv.w - strip * CW_COLS);
@@ -1000,7 +1005,7 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if ((tid & 63) == 0 && mine) atomicAdd(&s_tot, mine);
     __syncthreads();
-    if (tid == 0) pl.strip_tot[(size_t)f * g.total_strips + blockIdx.x] = s_tot;
+    if (tid == 0) pl.strip_tot[(size_t)f * g.total_strips + sx] = s_tot;
   } else {
     for (int i = tid; i < nslots; i += CW_COLS * LANES) {
       s_mask[i] = pl.cmask[l][slot0 + i];
@@ -1191,12 +1196,13 @@ __global__ void __launch_bounds__(1024) k_pcl_scan(int* chunk, int n, int* total
 // keeps their edge bits in a 32-bit mask: nearest edge above/below = clz / ffs on the mask, or the
 // LDS carry (last/first edge row of the other groups).  One edge read, one g^2 write per pixel.
 #define EDT_THREADS 1024
-__global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride) {
+__global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride, int nframes) {
   __shared__ int s_first[EDT_THREADS];  // [group][column]: first edge row of the group's segment (or +INF)
   __shared__ int s_last[EDT_THREADS];   // last edge row of the segment (or -INF)
-  const int f = f0 + blockIdx.z * fstride;
+  // 1-D grid, frame fastest (the strips of a frame share one XCD's L2, see k_compact_walk)
+  const int f = f0 + (blockIdx.x % nframes) * fstride;
   // decode (level, strip); taller levels use 32 groups x 32 columns, the others 16 x 64
-  int l = 0, sidx = blockIdx.x, ngroups = 16, ncols = 64;
+  int l = 0, sidx = blockIdx.x / nframes, ngroups = 16, ncols = 64;
   for (int k = 0; k < g.n_levels; ++k) {
     ngroups = g.lv[k].h > 512 ? 32 : 16;
     ncols = EDT_THREADS / ngroups;
@@ -1431,7 +1437,7 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  dim3 grid(g.total_strips, 1, B);
+  dim3 grid(g.total_strips * B);
   hipLaunchKernelGGL(k_compact_walk<false>, grid, dim3(CW_COLS * CW_LANES_COUNT), 0, s, g, p);
   hipLaunchKernelGGL(k_compact_walk<true>, grid, dim3(CW_COLS * CW_LANES), 0, s, g, p);
 }
@@ -1460,7 +1466,7 @@ void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride
     const int ncols = EDT_THREADS / (g.lv[l].h > 512 ? 32 : 16);
     strips += (g.lv[l].w + ncols - 1) / ncols;
   }
-  hipLaunchKernelGGL(k_edt_cols, dim3(strips, 1, count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride);
+  hipLaunchKernelGGL(k_edt_cols, dim3(strips * count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride, count);
   size_t rows_lds = 0;
   for (int l = 0; l < g.n_levels; ++l) rows_lds = std::max(rows_lds, (size_t)g.lv[l].edt_rows * (3 * g.lv[l].w + 8) * sizeof(int));
   hipLaunchKernelGGL(k_edt_rows, dim3(g.total_edt_blocks, 1, count), dim3(256), rows_lds, s, g, p, f0, fstride);

@@ -290,3 +290,17 @@ def test_bench_configuration_every_pair_against_the_oracle(api, ro):
           % (inside.sum(), n, drot.max(), dtr.max(), same_evals, n))
     assert inside.sum() >= n - 2
     assert drot.max() < 5e-3 and dtr.max() < 5e-3  # the slack of a borderline accept/stop decision, never more
+
+
+def test_shared_reciprocal_division_is_bit_identical_to_ieee(tmp_path):
+    """revo_div.h (one refined reciprocal shared by the divisions of a projection) returns the bits of __fdiv_rn on
+    2^26 operand pairs drawn from the tracker's ranges (tests/cpp/div_exact.hip, compiled here with hipcc)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "div_exact")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-w", "-o", exe,
+                           os.path.join(root, "tests", "cpp", "div_exact.hip")], timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "TOTAL_MISMATCHES 0" in out.stdout, out.stdout + out.stderr
