@@ -419,12 +419,7 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
 #define HA(i)
 #endif
 template <bool C_IN_LDS>
-#ifdef HYST_NUM_VGPR
-#define HYST_OCC __attribute__((amdgpu_num_vgpr(HYST_NUM_VGPR)))
-#else
-#define HYST_OCC
-#endif
-__global__ void __launch_bounds__(HYST_THREADS) HYST_OCC k_hyst(PyrGeom g, FramePlanes pl) {
+__global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl) {
   extern __shared__ uint32_t s_mem[];
 #ifdef REVO_HYST_PROFILE
   long long hp[12], ha[8], hlast = 0;
