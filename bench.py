@@ -136,8 +136,8 @@ def run_tum_stream(a, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pairs", type=int, default=32, help="frame-pairs per GPU per step")
     ap.add_argument("--buffers", type=int, default=2, help="batches in rotation (2 = double-buffered: build k+1 overlaps tracker k)")
     ap.add_argument("--width", type=int, default=640)
