@@ -2,12 +2,14 @@
 // (ImgPyramidRGBD ctor, imgpyramidrgbd.cpp:43-96,173-229) and the keyframe
 // promotion (makeKeyframe, imgpyramidrgbd.cpp:231-276).
 //
-// Integer/byte streaming and small stencils: coalesced dword/dwordx4 row accesses, an LDS
-// tile for the 3x3 stencil + union-find hysteresis, LDS staging where a block's output is a
-// contiguous range (ordered compaction), blockIdx.z = frame, blockIdx.x decodes level + tile
-// so one launch covers every level of every frame in the batch.  No MFMA: there is no
-// contraction anywhere on this path.  What binds each kernel (HBM for k_gray_depth, VALU issue for
-// k_canny_nms, dependent-load latency for the hysteresis passes, ...) is tabulated in DESIGN.md 3.
+// Integer/byte streaming and small stencils: coalesced dword/dwordx4 row accesses, the 3x3 stencil of
+// Canny entirely in registers (bitmaps out), hysteresis as a union-find over weak runs in the LDS of one
+// workgroup per (level, frame), 32 x 32 bit tiles transposed across lanes wherever a column-wise pass needs a
+// row-wise bitmap, LDS staging where a block's output is a contiguous range (ordered compaction).  One launch
+// covers every level of every frame in the batch; grids are 1-D and ordered so that the 8 XCDs (ids go
+// round-robin over them) either SHARE a frame's cache lines (frame-fastest: strips of one frame on one L2) or
+// SPREAD the expensive workgroups (level-major hysteresis).  No MFMA: there is no contraction anywhere on this
+// path.  What binds each kernel is tabulated in DESIGN.md 3.
 //
 // Exactness: every integer stage is bit-exact by construction; float stages
 // keep the reference's operation order and are compiled with -ffp-contract=off.
