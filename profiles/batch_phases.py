@@ -28,6 +28,14 @@ if __name__ == "__main__":
         bt.track_only(res.data_ptr(), stream=st.cuda_stream)
     torch.cuda.synchronize()
     ms = bt.time_tracker(res.data_ptr(), reps=10, stream=st.cuda_stream)
+    if os.environ.get("PH_OVERLAP"):  # the phase split NEXT TO a build of another batch (like the bench's steady state)
+        bt2 = api.BatchTracker(cam, NP)
+        sb = torch.cuda.Stream()
+        for _ in range(3):
+            bt2.build(bgr.data_ptr(), dep.data_ptr(), stream=sb.cuda_stream, borrow_depth=True)
+            bt.track_only(res.data_ptr(), stream=st.cuda_stream)
+            torch.cuda.synchronize()
+        print("(the numbers below: k_track running next to a build of 64 frames)")
     a = np.frombuffer(res.cpu().numpy().tobytes(), np.float32).reshape(NP, 24)
     ai = np.frombuffer(res.cpu().numpy().tobytes(), np.int32).reshape(NP, 24)
     us = 1.0 / 2400.0
