@@ -43,7 +43,7 @@ def scene(rng, w, h, kind):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
     bad = 0
     for i in range(n):
         w, h, lv, hist = SIZES[i % len(SIZES)] if i % 12 else SIZES[5]
