@@ -133,6 +133,49 @@ def run_tum_stream(a, device):
     return out
 
 
+def dry_run_cpu(a, world, rank, json_fd):
+    """The rank plumbing of this file without a GPU (gloo): spawn/rendezvous (done by the caller), static shard, one
+    96-byte record per pair from a stubbed step, the all_gather, max-over-ranks timing, ONE JSON line from rank 0.
+    No measurement: value is null and the line says dry_run."""
+    import torch
+    import torch.distributed as dist
+    from revo_amd import parallel
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(parallel.free_port()))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seeds = parallel.shard_pairs(world * a.pairs, rank, world)
+    rec = np.zeros((a.pairs, parallel.RECORD_BYTES // 4), np.float32)
+    rec[:, 0] = seeds   # what a tracker would write: here the pair's global index ...
+    rec[:, 9] = rank    # ... and the rank that "tracked" it
+    local = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
+    out = torch.empty(world * local.numel(), dtype=torch.uint8)
+    for _ in range(a.warmup):
+        parallel.gather_records(local, world, out=out)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = parallel.gather_records(local, world, out=out)
+    dist.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, world)
+    seen, wsz = parallel.ranks_seen(world)
+    g = got.numpy().view(np.float32).reshape(world * a.pairs, -1)
+    if not (np.array_equal(g[:, 0], np.arange(world * a.pairs, dtype=np.float32))
+            and np.array_equal(g[:, 9], np.repeat(np.arange(world, dtype=np.float32), a.pairs))):
+        raise SystemExit("bench --dry-run-cpu: the gather did not return every rank's records in rank order")
+    if rank == 0:
+        line = {"metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference", "value": None, "unit": "frames/s",
+                "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none (stubbed step)",
+                "config": {"workload": "orchestration dry run on CPU (gloo): no kernels", "pairs_per_gpu": a.pairs,
+                           "global_pairs": world * a.pairs},
+                "collective": {"backend": "gloo", "executed_every_step": True, "bytes_per_rank": a.pairs * parallel.RECORD_BYTES,
+                               "ranks_seen": seen, "world_size": wsz}}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +200,14 @@ def main():
     ap.add_argument("--tum-frames", type=int, default=200, help="frames of --tum-dir to run (0 = all)")
     ap.add_argument("--skip-host-buffers", action="store_true", help="skip the host-buffer (H2D-inclusive) side measurement")
     ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the world-size-1 RCCL group")
+    ap.add_argument("--input-batches", type=int, default=3,
+                    help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
+                         "than the 256 MB Infinity Cache, so 'resident in HBM' cannot mean 'resident in the last-level cache')")
+    ap.add_argument("--single-stream-runs", type=int, default=5, help="full-length runs of the sequential stream (median reported)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="orchestration check without a GPU: the rank plumbing of this file (spawn, rendezvous, shard, records, "
+                         "gather, max-over-ranks, one JSON line from rank 0) on the gloo backend with a stubbed step; the line "
+                         "carries dry_run=true and no measurement")
     a = ap.parse_args()
 
     from revo_amd import parallel
@@ -178,19 +229,25 @@ def main():
     os.dup2(2, 1)
     if "WORLD_SIZE" in os.environ and a.gpus != world and rank == 0:
         print("bench: --gpus %d ignored, the launcher set WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+    if a.dry_run_cpu:
+        return dry_run_cpu(a, world, rank, json_fd)
 
     # ---- synthetic input (rendered on the host BEFORE any GPU state exists) ----
     from revo_amd.settings import ImgPyramidSettings, TrackerSettings
     hist = tuple([20, 10, 5] + [0] * 3) if a.width == 640 else tuple([20, 10, 5, 0, 0, 0])
     s = ImgPyramidSettings.scaled(a.width, a.height, a.levels, hist_patch=hist)
     seeds = parallel.shard_pairs(world * a.pairs, rank, world)  # static block partition: rank g owns [g*B/G, (g+1)*B/G)
-    jobs = [(sd, a.width, a.height, a.levels) for sd in seeds]
-    nproc = a.render_procs or max(1, min(16, usable_cpus() // max(1, world), a.pairs))
+    # input batch j of this rank: the same shard of a disjoint seed range (batch 0 = seeds 0 .. world*pairs-1)
+    nin = max(1, a.input_batches)
+    jobs = [(j * world * a.pairs + sd, a.width, a.height, a.levels) for j in range(nin) for sd in seeds]
+    nproc = a.render_procs or max(1, min(16, usable_cpus() // max(1, world), len(jobs)))
     t0 = time.time()
     cache = a.input_cache and ("%s.r%d.npz" % (a.input_cache, rank))
     if cache and os.path.exists(cache):
         z = np.load(cache)
-        rendered = [(z["rb"][i], z["rd"][i], z["cb"][i], z["cd"][i], z["gt"][i]) for i in range(a.pairs)]
+        if len(z["rb"]) < len(jobs):
+            raise SystemExit("bench: %s holds %d pairs, %d are needed (delete it or lower --input-batches)" % (cache, len(z["rb"]), len(jobs)))
+        rendered = [(z["rb"][i], z["rd"][i], z["cb"][i], z["cd"][i], z["gt"][i]) for i in range(len(jobs))]
     elif nproc > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:
@@ -202,9 +259,12 @@ def main():
         np.savez(cache, rb=np.stack([r[0] for r in rendered]), rd=np.stack([r[1] for r in rendered]),
                  cb=np.stack([r[2] for r in rendered]), cd=np.stack([r[3] for r in rendered]),
                  gt=np.stack([r[4] for r in rendered]))
-    bgr = np.stack([r[k] for r in rendered for k in (0, 2)])
-    dep = np.stack([r[k] for r in rendered for k in (1, 3)])
-    gt = [r[4] for r in rendered]
+    rendered_all = rendered
+    bgrs = [np.stack([r[k] for r in rendered_all[j * a.pairs:(j + 1) * a.pairs] for k in (0, 2)]) for j in range(nin)]
+    deps = [np.stack([r[k] for r in rendered_all[j * a.pairs:(j + 1) * a.pairs] for k in (1, 3)]) for j in range(nin)]
+    gts = [[r[4] for r in rendered_all[j * a.pairs:(j + 1) * a.pairs]] for j in range(nin)]
+    rendered = rendered_all[:a.pairs]  # input batch 0: what the CPU baseline and the host-buffer legs use
+    bgr, dep = bgrs[0], deps[0]
 
     import torch
     import torch.distributed as dist
@@ -230,7 +290,7 @@ def main():
         stream_frames = [(f[0], f[1], f[2]) for f in seq]
         vo.REVO(s, cameraPyr=cam).run(stream_frames[:6])  # warm-up (pools, first-touch)
         runs = []
-        for _ in range(3):  # host-side jitter (threads, PCIe) is large for a 25 ms run: best of three, all reported
+        for _ in range(max(1, a.single_stream_runs)):  # all runs reported, the MEDIAN is the figure
             drv = vo.REVO(s, cameraPyr=cam)
             t0 = time.perf_counter()
             drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
@@ -267,8 +327,9 @@ def main():
     nbuf = 1 if a.no_overlap else max(2, a.buffers)
     bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf)]
     bt = bts[0]
-    d_bgr = torch.from_numpy(bgr).to(dev)
-    d_dep = torch.from_numpy(dep).to(dev)
+    d_bgrs = [torch.from_numpy(b).to(dev) for b in bgrs]
+    d_deps = [torch.from_numpy(d).to(dev) for d in deps]
+    d_bgr, d_dep = d_bgrs[0], d_deps[0]
     # every step keeps its own result records, so that ALL of them are checked after the timed region
     n_slots = a.warmup + a.steps
     d_res_all = torch.zeros(max(1, n_slots) * a.pairs * 96, dtype=torch.uint8, device=dev)
@@ -293,10 +354,11 @@ def main():
     def step():
         k = counter[0] % nbuf
         d_out = d_ress[counter[0] % len(d_ress)]
+        j_in = counter[0] % nin                      # the input batches rotate: step t reads input t mod nin
         counter[0] += 1
         if nbuf >= 2:
             s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
-            bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=s_build.cuda_stream, borrow_depth=True)
+            bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_build.cuda_stream, borrow_depth=True)
             ev_built[k].record(s_build)
             s_track.wait_event(ev_built[k])
             if timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
@@ -308,7 +370,7 @@ def main():
             else:
                 bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
         else:
-            bts[k].build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream, borrow_depth=True)
+            bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=stream, borrow_depth=True)
             bts[k].track_only(d_out.data_ptr(), stream=stream)
         ev_tracked[k].record(s_track)
         if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
@@ -351,26 +413,44 @@ def main():
     if bad_flags:
         raise SystemExit("bench: the tracker flagged invalid results (step, pair, flags): %s" % bad_flags[:8])
     res = all_res[(n_slots - 1) * a.pairs:]
-    first = all_res[:a.pairs]
-    if n_slots > 1 and any(not (np.array_equal(x["R"], y["R"]) and np.array_equal(x["T"], y["T"])) for x, y in zip(first, res)):
-        raise SystemExit("bench: the same inputs gave different poses in different steps")
-    errs = [synth.pose_error(r["R"], r["T"], g) for r, g in zip(res, gt)]
+    # step t read input batch t mod nin (on batch object t mod nbuf): equal inputs must give equal bits, whichever step
+    for t in range(nin, n_slots):
+        x, y = all_res[(t - nin) * a.pairs:(t - nin + 1) * a.pairs], all_res[t * a.pairs:(t + 1) * a.pairs]
+        if any(not (np.array_equal(p["R"], q["R"]) and np.array_equal(p["T"], q["T"])) for p, q in zip(x, y)):
+            raise SystemExit("bench: the same inputs gave different poses in steps %d and %d" % (t - nin, t))
+    errs = [synth.pose_error(r["R"], r["T"], g) for t in range(max(0, n_slots - nin), n_slots)
+            for r, g in zip(all_res[t * a.pairs:(t + 1) * a.pairs], gts[t % nin])]
     rot_med = float(np.median([e[0] for e in errs]))
     tr_med = float(np.median([e[1] for e in errs]))
 
     # ---- roofline of the dominant kernel (k_track): HIP events on its stream around every launch of the
     # timed region (next to the other stream's build kernels); `kernel_ms_alone` re-times it with nothing else
     # running (revo_batch_time_tracker)
-    ms_track_alone = bt.time_tracker(d_res.data_ptr(), reps=10, stream=stream)
-    ms_track = (float(np.mean([ea.elapsed_time(eb) for ea, eb in track_events])) if track_events else ms_track_alone)
-    npts = np.zeros((a.pairs, a.levels), np.int64)
-    for i in range(a.pairs):
-        view = bt.frame(2 * i + 1, s)
-        for lvl in range(a.levels):
-            npts[i, lvl] = view.return3DEdges(lvl).shape[0]
-    evals = np.array([r["evals"][: a.levels] for r in res], np.int64)
-    # B_trk = sum_l E_l*N_l*(16 + 4*16) + init check 2*N_c*(16+4)
-    b_trk = float((evals * npts * 80).sum() + (2 * npts[:, a.levels - 1] * 20).sum())
+    ms_track = (float(np.mean([ea.elapsed_time(eb) for ea, eb in track_events])) if track_events else None)
+    # algorithmic bytes per launch, SURVEY 8(d): B_trk = sum_l E_l*N_l*(16 + 4*16) + init check 2*N_c*(16+4) -- the mean
+    # over the input batches of the rotation (every one is rebuilt and tracked once more here, outside the timed
+    # region, to read its point counts; `kernel_ms_alone` averages over the same inputs)
+    b_trks, alone, npts_all, evals_all = [], [], [], []
+    for j in range(nin):
+        bt.build(d_bgrs[j].data_ptr(), d_deps[j].data_ptr(), stream=stream, borrow_depth=True)
+        alone.append(bt.time_tracker(d_res.data_ptr(), reps=max(2, 10 // nin), stream=stream))
+        torch.cuda.synchronize()
+        rj = api.results_from_buffer(d_res.cpu().numpy().tobytes(), a.pairs)
+        npts = np.zeros((a.pairs, a.levels), np.int64)
+        for i in range(a.pairs):
+            view = bt.frame(2 * i + 1, s)
+            for lvl in range(a.levels):
+                npts[i, lvl] = view.return3DEdges(lvl).shape[0]
+        evals = np.array([r["evals"][: a.levels] for r in rj], np.int64)
+        b_trks.append(float((evals * npts * 80).sum() + (2 * npts[:, a.levels - 1] * 20).sum()))
+        npts_all.append(npts)
+        evals_all.append(np.array([r["evals"] for r in rj], np.float64))
+    b_trk = float(np.mean(b_trks))
+    ms_track_alone = float(np.mean(alone))
+    if ms_track is None:
+        ms_track = ms_track_alone
+    npts = np.concatenate(npts_all)
+    evals = np.concatenate(evals_all)[:, : a.levels]
     achieved = b_trk / (ms_track * 1e-3) / 1e9  # GB/s
 
     # stage split (events around build-only / track-only, same stream)
@@ -417,6 +497,7 @@ def main():
             del src, dst
         except RuntimeError:
             copy_gbs = None
+    seen, group_size = parallel.ranks_seen(world, device=dev) if use_group else ([0], 1)
     gather_us = None
     if use_group:  # the collective alone (latency-bound: 96 B x pairs per rank)
         torch.cuda.synchronize()
@@ -459,12 +540,15 @@ def main():
         },
         "collective": {"backend": "nccl (RCCL)" if use_group else None, "executed_every_step": bool(use_group),
                        "bytes_per_rank": a.pairs * parallel.RECORD_BYTES, "us_per_all_gather_alone": gather_us,
+                       "ranks_seen": seen, "world_size": group_size,  # all_gather of the rank ids / dist.get_world_size()
                        "error": group_error},
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},
         "pose_error_vs_ground_truth": {"rot_rad_median": rot_med, "trans_m_median": tr_med},
         "mean_edge_points_lvl0": float(npts[:, 0].mean()),
         "mean_evals_per_level": [float(x) for x in evals.mean(0)],
-        "evals_raw_mean": [float(x) for x in np.array([r["evals"] for r in res], np.float64).mean(0)],
+        "evals_raw_mean": [float(x) for x in np.concatenate(evals_all).mean(0)],
+        "inputs": {"batches_in_rotation": nin, "bytes_per_batch": int(bgrs[0].nbytes + deps[0].nbytes),
+                   "note": "step t reads input batch t mod %d (distinct seeds); together they exceed the 256 MB Infinity Cache" % nin},
         "input_render_s": t_render,
     }
 
@@ -521,7 +605,7 @@ def main():
     # ---- the sequential stream measured at the start: its CPU counterpart and the record
     if seq_gpu is not None:
         n = n_seq
-        dt_seq = min(seq_gpu["runs"])
+        dt_seq = float(np.median(seq_gpu["runs"]))
         runs = seq_gpu["runs"]
         ate_seq = seq_gpu["ate"]
         rpe_t, rpe_r = seq_gpu["rpe"]
@@ -549,7 +633,8 @@ def main():
                 times_seq.append(ro.VO(s).run_pipelined(sb, sd, st, seq_pinned[0], seq_pinned[1])[0])
             seq_passes = len(times_seq) - 1
             cpu_seq_2core = nseq / float(np.median(times_seq[1:]))
-        out["single_stream"] = {"frames_per_s": n / dt_seq, "frames_per_s_runs": [n / t for t in runs], "frames": n,
+        out["single_stream"] = {"frames_per_s": n / dt_seq, "statistic": "median of %d runs" % len(runs),
+                                "frames_per_s_runs": [n / t for t in runs], "frames": n,
                                 "keyframes": seq_gpu["keyframes"],
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
                                 "rpe_rmse_per_frame": {"trans_m": rpe_t, "rot_rad": rpe_r},
@@ -567,7 +652,7 @@ def main():
     # ---- CPU baseline: the oracle (plain-C port of the reference's algorithm) on the same batch
     # with the reference's thread model -- the IO thread builds the pyramids, the main thread promotes keyframes and
     # tracks (system.cpp:96) -- each pinned to its own core, 1 warm-up + 5 passes, median.  Bounded: ~0.3 s per pass.
-    if rank == 0 and world == 1 and a.cpu_baseline != "off":
+    if rank == 0 and a.cpu_baseline != "off":  # at every N: measured once, on rank 0 (its input batch 0), after the timed region
         from oracle import ro
         model, allowed = cpu_info()
         pinned = [allowed[0], allowed[1 % len(allowed)]]
@@ -582,6 +667,7 @@ def main():
                       "plain-C restatement, gcc -O3 -mavx2, IO thread + tracker thread like the reference" % a.pairs,
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0 and world == 1 and a.cpu_baseline != "off":
         # one core (everything on the tracker's thread), same pinning, 1 warm-up + 3 passes
         trk = ro.Tracker(s)
         I3, Z3 = np.eye(3), np.zeros(3)

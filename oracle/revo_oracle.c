@@ -254,14 +254,18 @@ float ro_dist_histogram(const uint8_t* edges, int w, int h, int patch, uint8_t* 
   return (float)nz / (float)(hw * hh);
 }
 
-/* ImgPyramidRGBD::fillInEdges, imgpyramidrgbd.cpp:111-145. */
+/* ImgPyramidRGBD::fillInEdges, imgpyramidrgbd.cpp:111-145.  Finer-level pixels whose tile (yy/PATCH_SIZE_LOW,
+ * xx/PATCH_SIZE_LOW) lies beyond the coarse level's histogram are skipped: the reference indexes the cv::Mat out of
+ * bounds there (only when a level size is not a multiple of its patch size; never at 640x480).  Found by
+ * `make -C oracle sanitize`; librevo_hip's k_fill skips the same pixels. */
 void ro_fill_in_edges(const uint8_t* dist, int hist_w, const uint8_t* top_edges,
                       int top_w, int top_h, int patch, int patch_low,
                       uint8_t* edges_mod, int mod_w) {
   const int patch2 = patch * patch;
+  const int hist_h = (top_h / 2) / patch;
   for (int yy = 0; yy < top_h; ++yy)
     for (int xx = 0; xx < top_w; ++xx)
-      if ((yy % 2 == 1) && (xx % 2 == 1) &&
+      if ((yy % 2 == 1) && (xx % 2 == 1) && yy / patch_low < hist_h && xx / patch_low < hist_w &&
           (double)dist[(size_t)(yy / patch_low) * hist_w + (xx / patch_low)] < patch2 * 0.05) {
         if (top_edges[(size_t)yy * top_w + xx] > 0)
           edges_mod[(size_t)(yy / 2) * mod_w + (xx / 2)] = 255;

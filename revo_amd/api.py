@@ -379,8 +379,16 @@ class HostBatchTracker:
         arr = (PairIn * n)()
         keep = []
         want = np.uint16 if self.depth_scale_factor is not None else np.float32
+        # revo_track_pairs_submit takes H and W from the context and copies H rows of W pixels out of every buffer:
+        # a smaller or differently shaped frame would be read past its end
+        H, W = int(self._cam.settings.height), int(self._cam.settings.width)
+        if init_RT is not None and len(init_RT) != n:
+            raise ValueError("init_RT has %d entries for %d pairs" % (len(init_RT), n))
         for i, (ref, cur) in enumerate(pairs):
             for name, (bgr, dep) in (("ref", ref), ("cur", cur)):
+                if bgr.shape != (H, W, 3) or dep.shape != (H, W):
+                    raise ValueError("pair %d %s: frames must be BGR [%d,%d,3] and depth [%d,%d] (the context's size), got %s and %s"
+                                     % (i, name, H, W, H, W, tuple(bgr.shape), tuple(dep.shape)))
                 if bgr.dtype != np.uint8 or dep.dtype != want or bgr.strides[-1] != 1 or bgr.strides[-2] != 3 or dep.strides[-1] != dep.itemsize:
                     raise ValueError("frames must be uint8 BGR [H,W,3] and %s depth [H,W] with contiguous rows" % np.dtype(want).name)
                 keep += [bgr, dep]

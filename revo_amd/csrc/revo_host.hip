@@ -99,7 +99,7 @@ struct revo_ctx {
   // the kernel reads the descriptor from its argument segment and writes the result straight into
   // pinned host memory: one launch + one sync per trackFrames, no copies on the stream
   PairDesc* h_desc;
-  revo_pair_result* h_res;      // [2]: two single-pair launches may be in flight (the VO driver's look-ahead)
+  revo_pair_result* h_res;      // [3]: slots 0/1 = the VO driver's look-ahead launches, slot 2 = the public single-pair calls
   EvalOut* h_eval;
   unsigned* h_seq;              // [3] pinned: sequence words the kernels write after their results (2 tracker slots, vote)
   unsigned seq_next = 1;
@@ -393,7 +393,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHECK(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
-  HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result) * 2));
+  HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result) * 3));
   HIPCHECK(hipHostMalloc((void**)&c->h_seq, sizeof(unsigned) * 4));
   memset(c->h_seq, 0, sizeof(unsigned) * 4);
   HIPCHECK(hipHostMalloc((void**)&c->h_eval, sizeof(EvalOut)));
@@ -682,7 +682,8 @@ static int wait_seq(revo_ctx* c, volatile unsigned* word, unsigned want) {
   return REVO_OK;
 }
 
-// One single-pair tracker launch into result slot `slot` (0 / 1); *seq_out identifies it for track_wait.
+// One single-pair tracker launch into result slot `slot` (0 / 1: the VO driver's look-ahead, 2: the public single-pair
+// calls, which may run on a context whose VO driver keeps a speculative launch outstanding); *seq_out identifies it for track_wait.
 static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
                         const TrackParams& tp, int slot, unsigned* seq_out) {
   fill_desc(c->h_desc, ref, curr, R, T);
@@ -701,16 +702,17 @@ static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, 
 }
 static int track_wait(revo_ctx* c, int slot, unsigned seq) { return wait_seq(c, c->h_seq + slot, seq); }
 
+enum { SINGLE_SLOT = 2 };
 static int run_single(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float* R, const float* T,
                       const TrackParams& tp) {
   unsigned seq = 0;
-  int rc = track_launch(c, ref, curr, R, T, tp, 0, &seq);
+  int rc = track_launch(c, ref, curr, R, T, tp, SINGLE_SLOT, &seq);
   if (rc) return rc;
   if (tp.eval_only) {  // the EvalOut record is written by many lanes: wait for the stream, not for a word
     HIPCHECK(hipStreamSynchronize(c->stream));
     return REVO_OK;
   }
-  return track_wait(c, 0, seq);
+  return track_wait(c, SINGLE_SLOT, seq);
 }
 
 static int decode_track(const revo_pair_result& r, float R[9], float T[3], float* err, int* status, revo_residual_info* info,
@@ -755,7 +757,7 @@ extern "C" int revo_optimizer_track_level(revo_ctx* c, const revo_pyr* ref, cons
   tp.lvl_begin = tp.lvl_end = lvl; tp.check_init = 0; tp.eval_only = 0;
   rc = run_single(c, ref, curr, R, T, tp);
   if (rc) return rc;
-  return decode_track(c->h_res[0], R, T, err, nullptr, info, nullptr);
+  return decode_track(c->h_res[SINGLE_SLOT], R, T, err, nullptr, info, nullptr);
 }
 
 extern "C" int revo_optimizer_eval(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, const float R[9],
@@ -814,7 +816,7 @@ extern "C" int revo_tracker_track_frames(revo_ctx* c, const revo_pyr* ref, const
   tp.eval_only = 0;
   rc = run_single(c, ref, curr, R, T, tp);
   if (rc) return rc;
-  return decode_track(c->h_res[0], R, T, err, status, info, iters);
+  return decode_track(c->h_res[SINGLE_SLOT], R, T, err, status, info, iters);
 }
 
 // assessTrackingQuality (tracker.cpp:118-201) in two halves: enqueue the vote kernels / read the counts
@@ -1014,6 +1016,7 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   // (Splitting the batch into slices of pairs on 2 / 4 streams was measured in both rounds: no gain in round 1,
   // and with the round-2 kernels the step goes from 0.64 ms to 0.73 / 0.84 ms next to a tracker -- the build
   // kernels are throughput-limited, smaller launches only add tails.)
+  b->last_results = nullptr;  // records of an earlier launch are the caller's business again
   enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow);
   launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
   HIPCHECK(hipGetLastError());
@@ -1066,6 +1069,7 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   if (!(depth_scale_factor > 0.0)) return fail(REVO_ERR_INVALID_ARG, "depth_scale_factor must be positive");
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  b->last_results = nullptr;
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s);
   launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);
   HIPCHECK(hipGetLastError());
@@ -1092,6 +1096,7 @@ extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
   if (b->last_results) {
     HIPCHECK(hipMemcpyAsync(b->h_flags, b->last_results, sizeof(revo_pair_result) * b->n_pairs, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    b->last_results = nullptr;  // decoded once: the caller may free or reuse that buffer after this call
     for (int i = 0; i < b->n_pairs; ++i)
       if (b->h_flags[i].flags & 8)
         return fail(REVO_ERR_HIP, "tracker: pair " + std::to_string(i) + ": the workgroups of the pair could not exchange "
@@ -1192,6 +1197,18 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   // H2D straight from the caller's rows (no host-side staging copy): one copy per plane (strided only when the
   // rows are padded), colour planes and depth planes on two streams so that two DMA engines work
   hipStream_t cs = c->copy_stream, cs2 = c->copy_stream2;
+  // Any failure below must not leave the slot busy for ever (three of those and the context only ever answers
+  // REVO_ERR_CAPACITY), nor return while the DMA engines may still be reading the caller's buffers.
+  struct SlotGuard {
+    revo_ctx* c; revo_pairs_job* j; hipStream_t a, b;
+    ~SlotGuard() {
+      if (!j) return;
+      (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+      if (j->stream) (void)hipStreamSynchronize(j->stream);
+      std::lock_guard<std::mutex> lk(c->mu);
+      j->busy = false;
+    }
+  } slot_guard{c, j, cs, cs2};
   bool any_init = false;
   auto upload = [&](void* dst, const void* src, size_t src_stride, size_t row_bytes, hipStream_t st) -> hipError_t {
     if (src_stride == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * h, hipMemcpyHostToDevice, st);
@@ -1220,11 +1237,12 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   int rc = depth_is_u16 ? revo_batch_build_u16(j->batch, j->d_bgr, (const uint16_t*)j->d_depth, depth_scale_factor, s)
                         : revo_batch_build_borrow(j->batch, j->d_bgr, (const float*)j->d_depth, s);  // the job's own staging
   if (!rc) rc = revo_batch_track_only(j->batch, any_init ? j->h_init : nullptr, j->d_res, s);
-  if (rc) { j->busy = false; return rc; }
+  if (rc) return rc;
   HIPCHECK(hipMemcpyAsync(j->h_res, j->d_res, sizeof(revo_pair_result) * n, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipEventRecord(j->ev_done, s));
   // the caller's buffers are free again once the DMA has read them; the kernels keep running
   HIPCHECK(hipEventSynchronize(j->ev_h2d));
+  slot_guard.j = nullptr;
   *job_out = j;
   return REVO_OK;
 }

@@ -56,6 +56,19 @@ def max_over_ranks(seconds, world, device="cpu"):
     return float(t.item())
 
 
+def ranks_seen(world, device="cpu"):
+    """Every rank's id as the backend delivers it (one all_gather of one int64 per rank) plus the group's own idea of
+    its size: a SCALE line carries this as proof that N ranks really took part.  -> (list of ranks, world size)."""
+    import torch
+    import torch.distributed as dist
+    if not _group_live():
+        return [0], 1
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+    out = torch.empty(dist.get_world_size(), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(x) for x in out.cpu().tolist()], int(dist.get_world_size())
+
+
 def records_to_poses(buf, n):
     """uint8 numpy/bytes of n records -> (R [n,3,3] row-major, T [n,3], err [n])."""
     a = np.frombuffer(bytes(buf), dtype=np.float32).reshape(n, RECORD_BYTES // 4)

@@ -3,6 +3,7 @@ header declares (no compute calls without a GPU), struct layouts match the heade
 product fails loudly without a device, and the N>1 path (shard + gather + max-time) works
 with world_size 2 on gloo."""
 import ctypes as C
+import json
 import os
 import socket
 import subprocess
@@ -180,3 +181,43 @@ def test_cpp_adapters_compile_against_reference_shaped_types():
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "cpp", src)],
                            capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
+
+
+def _one_json_line(stdout):
+    lines = [ln for ln in stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # stdout carries exactly one line, the record
+    return json.loads(lines[0])
+
+
+def _check_dry_run_line(rec, world, pairs, steps):
+    assert rec["dry_run"] is True and rec["value"] is None  # never mistaken for a measurement
+    assert rec["n_gpus"] == world and rec["steps"] == steps and rec["scaling"] == "weak"
+    assert rec["config"]["global_pairs"] == world * pairs and rec["config"]["pairs_per_gpu"] == pairs
+    assert rec["collective"]["ranks_seen"] == list(range(world)) and rec["collective"]["world_size"] == world
+    assert rec["collective"]["bytes_per_rank"] == pairs * 96
+
+
+def test_bench_rank_plumbing_world2_self_spawned():
+    """`python bench.py --gpus 2` (no launcher): spawn -> rendezvous on 127.0.0.1 -> static shard -> one 96-byte record per
+    pair -> all_gather -> max-over-ranks -> ONE JSON line from rank 0, on gloo with a stubbed step: the
+    first real 8-GPU run cannot fail on orchestration."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "3",
+                        "--warmup", "1", "--pairs", "4"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check_dry_run_line(_one_json_line(r.stdout), 2, 4, 3)
+
+
+def test_bench_rank_plumbing_world2_under_torchrun():
+    """The driver's own launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu",
+                        "--steps", "2", "--warmup", "1", "--pairs", "3"], capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    rec = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(rec) == 1  # rank 0 only
+    _check_dry_run_line(rec[0], 2, 3, 2)

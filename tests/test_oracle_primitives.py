@@ -266,3 +266,18 @@ def test_quaternion_roundtrip_and_inverse():
     Rbad[0, 1] = 1e-3
     assert ro.lib().ro_is_orthogonal(ro._p(ro._cm3(np.eye(3)), ro.f32p)) == 1
     assert ro.lib().ro_is_orthogonal(ro._p(ro._cm3(Rbad), ro.f32p)) == 0
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """`make -C oracle sanitize` builds the oracle + oracle/selftest.c with -fsanitize=address,undefined and runs
+    it (pyramids, keyframe, trackFrames, coloured cloud, three VO frames, odd-sized primitives).  It found the reference's
+    out-of-bounds histogram read in fillInEdges on sizes that are not multiples of the patch size."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        import pytest
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"SELFTEST OK" in r.stdout, (r.stdout[-2000:] + r.stderr[-4000:]).decode()
