@@ -50,3 +50,22 @@ if __name__ == "__main__":
         print("  level %d: %.1f passes, %.1f us per pass, %.1f us in total" % (l, lvl_n[:, l].mean(), (lvl_us[:, l] / np.maximum(lvl_n[:, l], 1)).mean(), lvl_us[:, l].mean()))
     print("  phase totals per pair (us): eval %.1f [F %.1f | E %.1f]  barrier1 %.1f  sum+exchange %.1f  decision %.1f [logic %.1f | solve %.1f]"
           % (tot[:, 0].mean(), a[:, 8].mean() * us, a[:, 9].mean() * us, tot[:, 1].mean(), tot[:, 2].mean(), tot[:, 4].mean(), a[:, 10].mean() * us, a[:, 11].mean() * us))
+    try:  # the full per-level table (profile builds of round 3 on)
+        import ctypes
+        from revo_amd import _lib
+        buf = (ctypes.c_float * (64 * NP))()
+        if _lib.lib().revo_debug_batch_profile_(buf, NP) == 0:
+            t = np.array(buf, np.float32).reshape(NP, 64)
+            L = 6
+            print("  per level and pass (us):  eval | barrier+sums+exchange | decision")
+            for l in range(4):
+                n = np.maximum(t[:, 12 + L + l], 1)
+                print("    level %d: %5.2f | %5.2f | %5.2f" % (l, (t[:, 12 + 2 * L + l] / n).mean() * us, (t[:, 12 + 3 * L + l] / n).mean() * us,
+                                                          (t[:, 12 + 4 * L + l] / n).mean() * us))
+    except Exception as e:  # noqa: BLE001
+        print("  (no per-level phase table: %s)" % e)
+    if os.environ.get("PH_DUMP"):  # one line per pair: where the launch's tail comes from
+        print("pair  total_us passes | us per level 0..3 | passes per level 0..3")
+        for i in np.argsort(-lvl_us.sum(1)):
+            print("%4d  %7.1f %5d  | %s | %s" % (i, lvl_us[i].sum(), ai[i, 21], " ".join("%6.1f" % v for v in lvl_us[i]),
+                                              " ".join("%3d" % v for v in lvl_n[i])))

@@ -419,13 +419,24 @@ typedef const f4v __attribute__((address_space(1)))* gf4p;
 
 // 12 DT samples around (ix,iy): rows iy-1 (2), iy (4), iy+1 (4), iy+2 (2)
 struct DtPatch { float a0, a1, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1; };
+// 4-byte aligned vector types: the middle rows of the patch are ONE dwordx4 gather each (global loads only need
+// dword alignment) -- a gather instruction costs the vector L1 one tag lookup per distinct cache line among the 64
+// lanes, whatever its width, and that lookup rate is part of what bounds the evaluation of the fine levels
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef const f4u __attribute__((address_space(1)))* gf4up;
+typedef const f2u __attribute__((address_space(1)))* gf2up;
 __device__ __forceinline__ DtPatch load_patch(gf32p dt, int w, int ix, int iy) {
   gf32p p = dt + iy * w + ix;
   DtPatch q;
-  q.a0 = p[-w]; q.a1 = p[-w + 1];
-  q.b0 = p[-1]; q.b1 = p[0]; q.b2 = p[1]; q.b3 = p[2];
-  q.c0 = p[w - 1]; q.c1 = p[w]; q.c2 = p[w + 1]; q.c3 = p[w + 2];
-  q.d0 = p[2 * w]; q.d1 = p[2 * w + 1];
+  const f2u a = *(gf2up)(p - w);
+  const f4u b = *(gf4up)(p - 1);
+  const f4u c = *(gf4up)(p + w - 1);
+  const f2u d = *(gf2up)(p + 2 * w);
+  q.a0 = a.x; q.a1 = a.y;
+  q.b0 = b.x; q.b1 = b.y; q.b2 = b.z; q.b3 = b.w;
+  q.c0 = c.x; q.c1 = c.y; q.c2 = c.z; q.c3 = c.w;
+  q.d0 = d.x; q.d1 = d.y;
   return q;
 }
 
@@ -595,14 +606,16 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
                                                                    TrackParams prm, revo_pair_result* __restrict__ out,
                                                                    EvalOut* __restrict__ eval_out, u64* __restrict__ mail,
                                                                    int n_pairs, int cluster, unsigned epoch_base,
-                                                                   unsigned* seq_ptr, unsigned seq_val) {
+                                                                   unsigned* seq_ptr, unsigned seq_val, float* prof_out) {
   __shared__ Cand s_cand[2][KMAX];
   __shared__ PassCtl s_pass[2];
   __shared__ LMState s_st[2];
   __shared__ float s_part[NWAVES][NVAL];
   __shared__ int s_evals[REVO_L];  // residual evaluations per level, in the reference's count (wave 0 / lane 0 only)
 #ifdef REVO_TRACK_PROFILE
-  __shared__ long long s_prof[12 + 2 * REVO_L];  // [12 + l]: cycles spent in level l, [12 + REVO_L + l]: its passes
+  // [12 + l]: cycles spent in level l, [12 + L + l]: its passes, [12 + 2L + l]: evaluation, [12 + 3L + l]: barrier + sums +
+  // exchange, [12 + 4L + l]: decision (+ closing barrier) of level l
+  __shared__ long long s_prof[12 + 5 * REVO_L];
 #define PROF_MARK(var) const long long var = clock64()
 #else
 #define PROF_MARK(var)
@@ -674,7 +687,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       }
       s_pass[0] = pc;
 #ifdef REVO_TRACK_PROFILE
-      for (int i = 0; i < 12 + 2 * REVO_L; ++i) s_prof[i] = 0;
+      for (int i = 0; i < 12 + 5 * REVO_L; ++i) s_prof[i] = 0;
 #endif
     }
   }
@@ -976,6 +989,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       s_prof[0] += tp1 - tp0; s_prof[1] += tp2 - tp1; s_prof[2] += tp3 - tp2; s_prof[3] += 0; s_prof[4] += tp5 - tp3;
       s_prof[5] += tp6 - tp5;
       s_prof[12 + l] += tp6 - tp0; s_prof[12 + REVO_L + l] += 1;
+      s_prof[12 + 2 * REVO_L + l] += tp1 - tp0; s_prof[12 + 3 * REVO_L + l] += tp3 - tp1; s_prof[12 + 4 * REVO_L + l] += tp6 - tp3;
     }
 #endif
   }
@@ -1013,6 +1027,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       for (int i = 0; i < 4; ++i) { r.R[i] = (float)s_prof[12 + i]; r.R[4 + i] = (float)s_prof[12 + REVO_L + i]; }
       r.R[8] = (float)s_prof[6]; r.T[0] = (float)s_prof[7]; r.T[1] = (float)s_prof[8]; r.T[2] = (float)s_prof[9];
       r.err = (float)s_prof[10];
+    }
+    if (prof_out) {  // the whole table, per pair (revo_debug_batch_profile_)
+      for (int i = 0; i < 12 + 5 * REVO_L; ++i) prof_out[(size_t)pair * 64 + i] = (float)s_prof[i];
+      prof_out[(size_t)pair * 64 + 63] = (float)p;
     }
 #endif
     r.flags = s.flags;
@@ -1061,6 +1079,10 @@ int track_blocks_per_cu() {
 // launch gets a fresh window of TRACK_EPOCH_WINDOW epochs and stale granules of earlier launches can
 // never match.  The mailbox is zeroed when it is allocated and when the 32-bit counter would wrap.
 #define TRACK_EPOCH_WINDOW 8192u
+#ifdef REVO_TRACK_PROFILE
+static float* g_prof_dev = nullptr;
+static int g_prof_cap = 0;
+#endif
 static unsigned next_epoch_base(unsigned* epoch_io, unsigned long long* d_mail, size_t mail_bytes, hipStream_t s) {
   if (*epoch_io > 0xffffffffu - 2 * TRACK_EPOCH_WINDOW) {
     hipMemsetAsync(d_mail, 0, mail_bytes, s);
@@ -1076,8 +1098,28 @@ void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_res
   static_assert(MAX_TOTAL_EVALS + 64 < TRACK_EPOCH_WINDOW, "epoch window too small");
   const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * NVAL, s);
   const int groups = (n_pairs + 7) / 8;
+  float* prof = nullptr;
+#ifdef REVO_TRACK_PROFILE
+  if (g_prof_cap < n_pairs) {
+    if (g_prof_dev) (void)hipFree(g_prof_dev);
+    g_prof_cap = 0;
+    if (hipMalloc((void**)&g_prof_dev, sizeof(float) * 64 * (size_t)n_pairs) == hipSuccess) g_prof_cap = n_pairs;
+  }
+  prof = g_prof_cap >= n_pairs ? g_prof_dev : nullptr;
+#endif
   hipLaunchKernelGGL(k_track<false>, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, PairDesc{}, d_descs, prm, d_out,
-                     d_eval, (u64*)d_mail, n_pairs, cluster, base, (unsigned*)nullptr, 0u);
+                     d_eval, (u64*)d_mail, n_pairs, cluster, base, (unsigned*)nullptr, 0u, prof);
+}
+// profile builds: per pair 64 floats of cycle counters of the last batch launch (layout: k_track's s_prof, [63] = passes)
+extern "C" int revo_debug_batch_profile_(float* out, int n_pairs) {
+#ifdef REVO_TRACK_PROFILE
+  if (!out || n_pairs > g_prof_cap) return REVO_ERR_INVALID_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return REVO_ERR_HIP;
+  return hipMemcpy(out, g_prof_dev, sizeof(float) * 64 * (size_t)n_pairs, hipMemcpyDeviceToHost) == hipSuccess ? REVO_OK : REVO_ERR_HIP;
+#else
+  (void)out; (void)n_pairs;
+  return REVO_ERR_INVALID_ARG;
+#endif
 }
 
 // one pair, descriptor by value; out / eval_out may be device-visible pinned host memory
@@ -1086,5 +1128,5 @@ void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_re
                       hipStream_t s) {
   const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * 2 * (size_t)cluster * NVAL, s);
   hipLaunchKernelGGL(k_track<true>, dim3(8 * cluster), dim3(TRACK_THREADS), 0, s, desc, (const PairDesc*)nullptr, prm, out,
-                     eval_out, (u64*)d_mail, 1, cluster, base, seq_ptr, seq_val);
+                     eval_out, (u64*)d_mail, 1, cluster, base, seq_ptr, seq_val, (float*)nullptr);
 }
