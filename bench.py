@@ -336,6 +336,9 @@ def main():
     d_ress = [d_res_all[i * a.pairs * 96:(i + 1) * a.pairs * 96] for i in range(max(1, n_slots))]
     d_res = d_ress[0]
     s_track = torch.cuda.Stream(device=dev)
+    # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
+    # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
+    s_tracks = [s_track, torch.cuda.Stream(device=dev)] if (not a.no_overlap and not os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else [s_track]
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev) if nbuf >= 2 else s_track
     torch.cuda.set_stream(s_track)
@@ -355,24 +358,25 @@ def main():
         k = counter[0] % nbuf
         d_out = d_ress[counter[0] % len(d_ress)]
         j_in = counter[0] % nin                      # the input batches rotate: step t reads input t mod nin
+        s_tr = s_tracks[counter[0] % len(s_tracks)]
         counter[0] += 1
         if nbuf >= 2:
             s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
             bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_build.cuda_stream, borrow_depth=True)
             ev_built[k].record(s_build)
-            s_track.wait_event(ev_built[k])
+            s_tr.wait_event(ev_built[k])
             if timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
                 e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e_a.record(s_track)
-                bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
-                e_b.record(s_track)
+                e_a.record(s_tr)
+                bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
+                e_b.record(s_tr)
                 track_events.append((e_a, e_b))
             else:
-                bts[k].track_only(d_out.data_ptr(), stream=s_track.cuda_stream)
+                bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
         else:
             bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=stream, borrow_depth=True)
             bts[k].track_only(d_out.data_ptr(), stream=stream)
-        ev_tracked[k].record(s_track)
+        ev_tracked[k].record(s_tr)
         if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
             # nothing on the device waits for it (the host reads the gathered records after the run), so it is off the
             # tracker stream's chain; it is inside the timed region all the same (synchronize + barrier below)
@@ -527,7 +531,8 @@ def main():
                         % (a.width, a.height, a.levels, a.pairs, 2 if world == 1 else 4),
             "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
             "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
-            "pipelining": "none" if a.no_overlap else "double-buffered: build of step k+1 overlaps tracker of step k",
+            "pipelining": "none" if a.no_overlap else ("double-buffered: build of step k+1 overlaps tracker of step k; consecutive tracker "
+                                                        "grids on %d stream(s), ordered by the library's resident gate" % len(s_tracks)),
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

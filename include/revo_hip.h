@@ -171,7 +171,9 @@ typedef enum revo_plane {
   REVO_PLANE_DT = 4,         /* returnDistTransform(lvl)   f32 W*H (keyframe) */
   REVO_PLANE_GRADTABLE = 5,  /* returnOptimizationStructure(lvl) f32 4*W*H    */
   REVO_PLANE_EDGES3D = 6,    /* return3DEdges(lvl)         f32 4*N col-major  */
-  REVO_PLANE_HIST = 7        /* histPyr[lvl]               u8  (H/P)*(W/P)    */
+  REVO_PLANE_HIST = 7,       /* histPyr[lvl]               u8  (H/P)*(W/P)    */
+  REVO_PLANE_EDGES3D_TILED = 8 /* the same N points as EDGES3D in the order the tracker reads them (32x32-pixel tiles in raster
+                                  order, row-major inside a tile): what the per-frame build writes; EDGES3D is derived on demand */
 } revo_plane;
 
 /* Lazy device->host read of one accessor plane.  cap_bytes = size of host_dst;

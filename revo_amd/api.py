@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import RevoError, check, f32p, i32p, u8p, u16p, vp
 from .settings import (ImgPyramidSettings, OptimizerSettings, TrackerSettings, ResidualInfo, PairResult, PairIn,
                        MAX_LEVELS, PLANE_GRAY, PLANE_DEPTH, PLANE_EDGES, PLANE_EDGES_ORIG, PLANE_DT,
-                       PLANE_GRADTABLE, PLANE_EDGES3D, PLANE_HIST, TRACKER_STATE_OK, TRACKER_STATE_NEW_KF)
+                       PLANE_GRADTABLE, PLANE_EDGES3D, PLANE_HIST, PLANE_EDGES3D_TILED, TRACKER_STATE_OK, TRACKER_STATE_NEW_KF)
 
 
 def _p(a, t):
@@ -82,7 +82,7 @@ class CameraPyr:
 
 _DT = {PLANE_GRAY: (np.uint8, 1), PLANE_DEPTH: (np.float32, 1), PLANE_EDGES: (np.uint8, 1),
        PLANE_EDGES_ORIG: (np.uint8, 1), PLANE_DT: (np.float32, 1), PLANE_GRADTABLE: (np.float32, 4),
-       PLANE_EDGES3D: (np.float32, 4), PLANE_HIST: (np.uint8, 1)}
+       PLANE_EDGES3D: (np.float32, 4), PLANE_HIST: (np.uint8, 1), PLANE_EDGES3D_TILED: (np.float32, 4)}
 
 
 class ImgPyramidRGBD:
@@ -134,7 +134,7 @@ class ImgPyramidRGBD:
         if n.value:
             check(_lib.lib().revo_pyramid_read(self._h, what, lvl, buf.ctypes.data_as(vp), buf.nbytes, C.byref(n)))
         w, h = self.mSettings.level_size(lvl)
-        if what == PLANE_EDGES3D or n.value == 0:
+        if what in (PLANE_EDGES3D, PLANE_EDGES3D_TILED) or n.value == 0:
             return buf
         if what == PLANE_HIST:
             p = self.mSettings.hist_patch[lvl]
@@ -160,6 +160,11 @@ class ImgPyramidRGBD:
     def return3DEdges(self, lvl):
         """N x 4 float32 rows (X,Y,Z,1) == the columns of the reference's 4xN Eigen::MatrixXf."""
         return self._read(PLANE_EDGES3D, lvl)
+
+    def edges3DTiled(self, lvl):
+        """The same N points as return3DEdges in the order the tracker reads them: 32x32-pixel tiles in raster order,
+        row-major inside a tile (what the per-frame build writes; not a reference accessor)."""
+        return self._read(PLANE_EDGES3D_TILED, lvl)
 
     def generateColoredPcl(self, lvl, densePcl=False):
         """imgpyramidrgbd.cpp:279-327: N x 8 float32 rows (X,Y,Z,1,r,g,b,1), colours in [0,1] ==

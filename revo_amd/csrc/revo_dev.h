@@ -36,6 +36,7 @@ struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
   int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
+  int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
   int use_edge_hist;
@@ -52,7 +53,8 @@ struct FramePlanes {
   uint8_t* edges[REVO_L];      // edgesPyr     {0,255}
   uint8_t* edges_orig[REVO_L]; // edgesOrigPyr {0,255}: written only for levels with has_orig (elsewhere it IS edges)
   int* scratch[REVO_L];        // CCL parent keys during the build; column g^2 during makeKeyframe
-  float4* pts[REVO_L];         // edges3DPyr: (X,Y,Z,1), capacity npix per frame
+  float4* pts[REVO_L];         // edges3DPyr: (X,Y,Z,1), capacity npix per frame -- the reference's order, built on demand
+  float4* pts_trk[REVO_L];     // the same points tile-ordered (hot path: what the tracker and the vote read)
   float* dt[REVO_L];           // dtPyr
   float4* table[REVO_L];       // optimizationStructure
   uint8_t* hist[REVO_L];       // histPyr (frame stride hist_w*hist_h)
@@ -63,6 +65,7 @@ struct FramePlanes {
   int* npts;                   // [B][REVO_L]
   int* hist_nz;                // [B][REVO_L]
   int* strip_tot;              // [B][total_strips]: edge points per 64-column strip (the compaction's cross-strip offsets)
+  int* tile_base;              // [B][total_tiles]: first list position of every 32 x 32 tile (exclusive scan per level)
 };
 
 // One frame-pair for the tracker kernel.
@@ -120,19 +123,24 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
-void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
+void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);      // reference-ordered list (accessor)
+void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);  // tile-ordered list + npts (hot path)
 // keyframe promotion of frames f0, f0+fstride, ... (count frames)
 void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
 void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int lvl, int dense, const uint8_t* bgr_lvl,
                         int* chunk, unsigned* cmask, int* total, int cap, float* out8, hipStream_t s);
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
 // epoch_io: per-mailbox epoch counter kept by the owner of d_mail (zero it together with the mailbox)
-void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
-                  int n_pairs, unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s);
+// both tracker launchers return the grid size (workgroups) they enqueued; d_resident: the device's census counter (every
+// workgroup adds 1 when it starts), nullptr = no census
+int launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
+                 int n_pairs, unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* d_resident, hipStream_t s);
+// waits on the device until the census counter has reached `want`
+void launch_track_gate(const unsigned* d_resident, unsigned want, hipStream_t s);
 // seq_ptr (pinned host memory, may be null): receives seq_val after the result record has been written
-void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
-                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,
-                      hipStream_t s);
+int launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
+                     unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,
+                     unsigned* d_resident, hipStream_t s);
 void launch_solve6(const float* d_Ab /*n x 43: A 36, b 6, lambda*/, int n, float* d_x /*n x 6*/, hipStream_t s);
 int track_blocks_per_cu();  // occupancy query of k_track (advisory)
 void launch_grad_table(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);

@@ -125,6 +125,7 @@ struct revo_pyr {
   bool is_kf;
   double ts;
   bool table_built;
+  bool ref_list_built;  // edges3DPyr in the reference's order (the hot path only writes the tile-ordered list)
 };
 
 struct revo_batch {
@@ -165,7 +166,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   if (hi > 0) hi *= hi;
   g->canny_low = (int)std::floor(lo); g->canny_high = (int)std::floor(hi);
   g->use_edge_hist = s.use_edge_hist; g->n_percentage = s.n_percentage;
-  int tile = 0, pix = 0, row = 0, col = 0, cc = 0;
+  int tile = 0, pix = 0, row = 0, col = 0, cc = 0, tiles32 = 0;
   for (int l = 0; l < L; ++l) {
     LevelGeom& v = g->lv[l];
     const float scale = 1.0f / (float)std::pow(2, l);  // camerapyr.h:142
@@ -192,7 +193,9 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     v.edt_block_base = row; row += (v.h + v.edt_rows - 1) / v.edt_rows;
     v.strip_base = col; col += (v.w + 63) / 64;
     v.cc_base = cc; cc += v.w * v.nchunk;
+    tiles32 += v.wpr * v.nchunk;
   }
+  g->total_tiles = tiles32;
   for (int l = 1; l < L; ++l)  // fillInEdges' gate (imgpyramidrgbd.cpp:188-195 + the patch sizes that exist)
     g->lv[l].has_orig = (s.use_edge_hist && g->lv[l].patch > 0 && g->lv[l - 1].patch > 0) ? 1 : 0;
   g->total_nms_blocks = tile; g->total_pix = pix; g->total_edt_blocks = row; g->total_strips = col; g->total_cc = cc;
@@ -257,30 +260,55 @@ static int pick_cluster(const revo_ctx* c, int n_pairs) {
   return cl;
 }
 
-// Tracker launches of one device are chained: a cluster's workgroups exchange partial sums inside the
-// launch, so two tracker grids must never be partially resident at the same time (each would wait for
-// members the other keeps off the CUs until the bounded spin gives up with flag 8).  A launch on another
-// stream than the previous one first waits for the previous tracker's event; launches on one stream are
-// ordered by the stream itself.  (Other PROCESSES sharing the GPU are outside this library's reach: the
-// bounded spin + flag 8 + REVO_ERR_HIP remain the answer there.)
+// Tracker launches of one device are ordered by a RESIDENT GATE.  A cluster's workgroups exchange partial sums inside
+// the launch, so two tracker grids must never be PARTIALLY resident at the same time (each would wait for members the
+// other keeps off the CUs until the bounded spin gives up with flag 8).  Round 2 serialised the grids completely (launch
+// n waited for launch n-1 to finish) -- and a launch lasts as long as its slowest pair (455 us against a mean of 294 us
+// per pair), so a third of the tracker's CU time idled behind the tail.  Now launch n
+//   * waits for launch n-2 to COMPLETE (at most two tracker grids are ever in flight), and
+//   * waits, through a one-wave gate kernel in front of it, until every workgroup of launch n-1 has STARTED
+//     (k_track counts its workgroups into a per-device census counter as they start).  A started workgroup holds its CU
+//     until it exits, so from then on launch n-1 is complete on the chip and makes progress whatever else arrives;
+//     launch n's workgroups fill the CUs that n-1's finished pairs free, and are themselves all resident once n-1 has
+//     drained (192 <= 256 CUs; build kernels finish in finite time).  By induction the older of the two grids is always
+//     fully resident: no cyclic wait.
+// REVO_TRACK_SERIAL=1 restores the round-2 behaviour.  (Other PROCESSES sharing the GPU are outside this library's
+// reach: the bounded spin + flag 8 + REVO_ERR_HIP remain the answer there.)
 struct TrackChain {
   std::mutex mu;
-  hipEvent_t ev = nullptr;
-  hipStream_t last = nullptr;
-  bool has = false;
+  hipEvent_t ev[2] = {nullptr, nullptr};  // completion of the last two launches (ring)
+  hipStream_t st[2] = {nullptr, nullptr};
+  bool has[2] = {false, false};
+  int n = 0;                     // launches so far
+  unsigned* d_resident = nullptr;
+  unsigned started_total = 0;    // workgroups of all launches enqueued so far (the census value once they have all started)
+  int serial = -1;
 };
 static TrackChain g_chain[64];
+// launch(): enqueues the tracker grid on s and returns its workgroup count
 template <typename F>
 static int chained_track_launch(int device, hipStream_t s, F&& launch) {
   TrackChain& ch = g_chain[device & 63];
   std::lock_guard<std::mutex> lk(ch.mu);
-  if (!ch.ev) HIPCHECK(hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming));
-  if (ch.has && ch.last != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev, 0));
-  launch();
+  if (ch.serial < 0) { const char* e = getenv("REVO_TRACK_SERIAL"); ch.serial = (e && *e && *e != '0') ? 1 : 0; }
+  if (!ch.ev[0]) {
+    HIPCHECK(hipEventCreateWithFlags(&ch.ev[0], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&ch.ev[1], hipEventDisableTiming));
+    HIPCHECK(hipMalloc((void**)&ch.d_resident, sizeof(unsigned)));
+    HIPCHECK(hipMemset(ch.d_resident, 0, sizeof(unsigned)));
+  }
+  const int cur = ch.n & 1, prev = cur ^ 1;  // slot `cur` holds launch n-2, slot `prev` launch n-1
+  if (ch.has[cur] && ch.st[cur] != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev[cur], 0));  // n-2 complete
+  if (ch.has[prev] && ch.st[prev] != s) {
+    if (ch.serial) HIPCHECK(hipStreamWaitEvent(s, ch.ev[prev], 0));                     // n-1 complete (round-2 behaviour)
+    else launch_track_gate(ch.d_resident, ch.started_total, s);                         // n-1 fully resident
+  }
+  ch.started_total += (unsigned)launch(ch.d_resident);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipEventRecord(ch.ev, s));
-  ch.has = true;
-  ch.last = s;
+  HIPCHECK(hipEventRecord(ch.ev[cur], s));
+  ch.has[cur] = true;
+  ch.st[cur] = s;
+  ch.n += 1;
   return REVO_OK;
 }
 static size_t mail_bytes(int n_pairs, int cluster) { return sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * TRACK_NVAL; }
@@ -310,6 +338,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       fs->p.edges_orig[l] = (uint8_t*)take(n);
       fs->p.scratch[l] = (int*)take(n * 4);
       fs->p.pts[l] = (float4*)take(n * 16);
+      fs->p.pts_trk[l] = (float4*)take(n * 16);
       fs->p.dt[l] = (float*)take(n * 4);
       fs->p.table[l] = (float4*)take(n * 16);
       fs->p.hist[l] = (uint8_t*)take((size_t)std::max(1, v.hist_w * v.hist_h) * B);
@@ -321,6 +350,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.hist_nz = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.strip_tot = (int*)take(sizeof(int) * (size_t)g.total_strips * B);
+    fs->p.tile_base = (int*)take(sizeof(int) * (size_t)g.total_tiles * B);
     if (with_staging) {
       fs->d_bgr = (uint8_t*)take((size_t)g.lv[0].npix * 3 * B);
       fs->d_depth = (float*)take((size_t)g.lv[0].npix * 4 * B);
@@ -368,7 +398,7 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
   launch_canny_nms(g, fs->p, B, s);
   launch_hyst(g, fs->p, B, s);
   launch_fill(g, fs->p, B, s);
-  launch_compact(g, fs->p, B, s);
+  launch_tile_points(g, fs->p, B, s);  // the tracker's (tile-ordered) edge list; the reference's order is built on demand
 }
 
 // ------------------------------------------------------------------ context --
@@ -511,7 +541,7 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_ready, bs));
   fs->has_ready = true;
-  revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts, false};
+  revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts, false, false};
   ctx_ref(c);
   *out = p;
   return REVO_OK;
@@ -588,9 +618,22 @@ extern "C" int revo_pyramid_read(revo_pyr* p, revo_plane what, int lvl, void* ds
       }
       src = P.table[lvl] + f * v.npix; esz = 16; break;
     case REVO_PLANE_EDGES3D: {
+      if (!p->ref_list_built) {  // the reference's column-major order (imgpyramidrgbd.cpp:199-226): materialised for the accessor
+        PyrGeom g1 = c->geom;
+        g1.frame0 = p->frame;
+        launch_compact(g1, P, 1, c->stream);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        p->ref_list_built = true;
+      }
       int np = 0;
       HIPCHECK(hipMemcpy(&np, P.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToHost));
       n = (size_t)np; src = P.pts[lvl] + f * v.npix; esz = 16; break;
+    }
+    case REVO_PLANE_EDGES3D_TILED: {
+      int np = 0;
+      HIPCHECK(hipMemcpy(&np, P.npts + f * REVO_L + lvl, sizeof(int), hipMemcpyDeviceToHost));
+      n = (size_t)np; src = P.pts_trk[lvl] + f * v.npix; esz = 16; break;
     }
     case REVO_PLANE_HIST:
       if (v.patch <= 0) { n = 0; src = P.hist[lvl]; break; }
@@ -654,7 +697,7 @@ static void fill_desc(PairDesc* d, const revo_pyr* ref, const revo_pyr* curr, co
   const PyrGeom& g = ref->ctx->geom;
   memset(d, 0, sizeof(*d));
   for (int l = 0; l < g.n_levels; ++l) {
-    d->pts[l] = curr->fs->p.pts[l] + (size_t)curr->frame * g.lv[l].npix;
+    d->pts[l] = curr->fs->p.pts_trk[l] + (size_t)curr->frame * g.lv[l].npix;
     d->dt[l] = ref->fs->p.dt[l] + (size_t)ref->frame * g.lv[l].npix;
   }
   d->npts = curr->fs->p.npts + (size_t)curr->frame * REVO_L;
@@ -692,9 +735,9 @@ static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, 
   tp1.redundant_n = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
   const unsigned seq = c->seq_next++;
   if (c->seq_next == 0) c->seq_next = 1;
-  const int rc = chained_track_launch(c->device, c->stream, [&] {
-    launch_track_one(*c->h_desc, tp1, c->h_res + slot, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->h_seq + slot, seq,
-                     c->stream);
+  const int rc = chained_track_launch(c->device, c->stream, [&](unsigned* d_resident) {
+    return launch_track_one(*c->h_desc, tp1, c->h_res + slot, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->h_seq + slot,
+                            seq, d_resident, c->stream);
   });
   if (rc) return rc;
   *seq_out = seq;
@@ -919,7 +962,7 @@ extern "C" int revo_tracker_add_old_pcl(revo_ctx* c, const revo_pyr* src, int lv
   const size_t f = (size_t)src->frame;
   { int rc = past_take(c, (size_t)c->geom.lv[lvl].npix, &p); if (rc) return rc; }
   // the count stays on the device: one kernel copies the n valid points and n (stream ordered)
-  launch_copy_cloud(p.d_pts, src->fs->p.pts[lvl] + f * c->geom.lv[lvl].npix, p.d_n, src->fs->p.npts + f * REVO_L + lvl,
+  launch_copy_cloud(p.d_pts, src->fs->p.pts_trk[lvl] + f * c->geom.lv[lvl].npix, p.d_n, src->fs->p.npts + f * REVO_L + lvl,
                     c->stream);
   HIPCHECK(hipGetLastError());
   p.n = -1;
@@ -984,7 +1027,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   b->cluster = pick_cluster(c, n_pairs);
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
-  for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false});
+  for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false, false});
   HIPCHECK(hipHostMalloc((void**)&b->h_descs, sizeof(PairDesc) * n_pairs));
   HIPCHECK(hipHostMalloc((void**)&b->h_flags, sizeof(revo_pair_result) * n_pairs));
   HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
@@ -1022,7 +1065,7 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;
-  for (auto& v : b->views) v.table_built = false;
+  for (auto& v : b->views) { v.table_built = false; v.ref_list_built = false; }
   return REVO_OK;
 }
 extern "C" int revo_batch_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream) {
@@ -1056,8 +1099,8 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
   b->last_results = d_results;
-  return chained_track_launch(b->ctx->device, s, [&] {
-    launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
+  return chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
+    return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
   });
 }
 
@@ -1075,7 +1118,7 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;
-  for (auto& v : b->views) v.table_built = false;
+  for (auto& v : b->views) { v.table_built = false; v.ref_list_built = false; }
   return REVO_OK;
 }
 
@@ -1291,8 +1334,8 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
-    rc = chained_track_launch(b->ctx->device, s, [&] {
-      launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, s);
+    rc = chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
+      return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
     });
     if (rc) return rc;
     HIPCHECK(hipEventRecord(b->ev1, s));

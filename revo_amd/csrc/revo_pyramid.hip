@@ -1078,6 +1078,160 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
   }
 }
 
+// ---------------------------------------------------------------------------
+// a8 for the tracker: the same points as the ordered list (imgpyramidrgbd.cpp:199-226), TILE-ORDERED.
+// The reference's list is column-major (x outer, y inner): 64 consecutive entries -- one wavefront of the tracker --
+// sit in ~1.7 image columns and span every row, so each of the tracker's gather instructions touched ~44 different
+// cache lines (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD) and a workgroup's 512 points walked the whole height of the
+// keyframe's DT plane.  The tracker does not care about the order of its sum, only the accessor does: the hot path
+// now writes the points grouped by 32 x 32-pixel tiles (tiles in raster order, row-major inside a tile) -- a
+// wavefront's points share a handful of DT rows -- and the reference-ordered list is produced on demand by the walk
+// above (revo_pyramid_read, EDGES3D).  Both lists hold the same points with the same bits.
+//   k_tile_count : one workgroup per (level, frame); thread = row of a tile (32-pixel word of the edge bitmap AND the
+//                  depth-validity bits; the coarsest level, which has no validity bits, tests its depths), tile totals,
+//                  an exclusive scan over the level's tiles -> tile_base, the level's point count -> npts
+//   k_pts_tiles  : half a wavefront per tile; the tile's 32 x 32 depths go through LDS (rows loaded 128 B at a time
+//                  instead of one sparse gather per point), each lane emits the points of its row
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tile_valid_word(const PyrGeom& g, const FramePlanes& pl, int l, int f, int y, int wc, uint32_t E) {
+  // depth-validity bits of pixels 32*wc .. 32*wc+31 of row y (levels below the coarsest: written by k_pyrdown)
+  const LevelGeom& lv = g.lv[l];
+  const uint8_t* vb = pl.vb[l] + (size_t)f * (lv.npix >> 3) + (size_t)y * (lv.w >> 3);
+  if ((lv.w & 31) == 0) return E & *reinterpret_cast<const uint32_t*>(vb + 4 * wc);
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (32 * wc + 8 * k < lv.w) v |= (uint32_t)vb[4 * wc + k] << (8 * k);
+  return E & v;
+}
+__device__ __forceinline__ int level_tile_base(const PyrGeom& g, int l) {  // tiles of finer levels (32 x 32 px, raster order)
+  int b = 0;
+  for (int k = 0; k < l; ++k) b += g.lv[k].wpr * g.lv[k].nchunk;
+  return b;
+}
+
+__global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) {
+  __shared__ int s_tile[2048];   // per tile: count, then exclusive base (levels up to 2048 x 1024: 64 x 32 tiles)
+  __shared__ int s_wsum[16];
+  const int nB = gridDim.x / g.n_levels;
+  const int l = blockIdx.x / nB;
+  const int f = g.frame0 + blockIdx.x % nB;
+  const LevelGeom& lv = g.lv[l];
+  const int wpr = lv.wpr, h = lv.h, ntiles = wpr * lv.nchunk;
+  const bool has_vb = l < g.n_levels - 1;
+  const uint2* csw = pl.cs[l] + (size_t)f * h * wpr;
+  const float* depth = pl.depth[l] + (size_t)f * lv.npix;
+  const int tid = threadIdx.x, r = tid & 31;
+  for (int i = tid; i < ntiles; i += 1024) s_tile[i] = 0;
+  __syncthreads();
+  // half-waves take tiles round-robin; lane r = row r of the tile
+  for (int t = tid >> 5; t < ntiles; t += 32) {
+    const int c = t / wpr, wc = t - c * wpr;
+    const int y = c * 32 + r;
+    uint32_t v = 0;
+    if (y < h) {
+      const uint32_t E = csw[(size_t)y * wpr + wc].y;
+      if (has_vb) v = tile_valid_word(g, pl, l, f, y, wc, E);
+      else
+        for (uint32_t m = E; m; m &= m - 1) {  // the coarsest level: a few thousand pixels per frame
+          const int b = __ffs(m) - 1;
+          if (depth_ok(depth[(size_t)y * lv.w + 32 * wc + b], g.depth_min, g.depth_max)) v |= 1u << b;
+        }
+    }
+    int cnt = __popc(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 32);
+    if (r == 0) s_tile[t] = cnt;
+  }
+  __syncthreads();
+  // exclusive scan over the level's tiles (<= 2 per thread)
+  const int i0 = 2 * tid, i1 = 2 * tid + 1;
+  const int c0 = i0 < ntiles ? s_tile[i0] : 0, c1 = i1 < ntiles ? s_tile[i1] : 0;
+  int incl = c0 + c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += u;
+  }
+  if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+  __syncthreads();
+  int pre = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { const int wv = s_wsum[k]; pre += k < (tid >> 6) ? wv : 0; total += wv; }
+  const int ex = pre + incl - (c0 + c1);
+  int* tb = pl.tile_base + (size_t)f * g.total_tiles + level_tile_base(g, l);
+  if (i0 < ntiles) tb[i0] = ex;
+  if (i1 < ntiles) tb[i1] = ex + c0;
+  if (tid == 0) pl.npts[f * REVO_L + l] = total;
+}
+
+#define PT_TILES 8                 // tiles (half-waves) per block of k_pts_tiles
+#define PT_PITCH 36                // floats per staged depth row (16-byte aligned rows, banks spread)
+__global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
+  __shared__ float s_depth[PT_TILES][32 * PT_PITCH];
+  // 1-D grid, frame fastest (the tile groups of a frame share one XCD's L2)
+  const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
+  const int nB = gridDim.x / groups;
+  const int f = g.frame0 + blockIdx.x % nB;
+  const int tg = (blockIdx.x / nB) * PT_TILES + (threadIdx.x >> 5);
+  if (tg >= g.total_tiles) return;
+  int l = 0, t = tg;
+  for (int k = 0; k < g.n_levels; ++k) {
+    const int n = g.lv[k].wpr * g.lv[k].nchunk;
+    if (t < n) { l = k; break; }
+    t -= n;
+  }
+  const LevelGeom& lv = g.lv[l];
+  const int wpr = lv.wpr, h = lv.h, w = lv.w;
+  const int c = t / wpr, wc = t - c * wpr;
+  const int r = threadIdx.x & 31;
+  const int y0 = c * 32, x0 = wc * 32, y = y0 + r;
+  const bool has_vb = l < g.n_levels - 1;
+  const uint2* csw = pl.cs[l] + (size_t)f * h * wpr;
+  const float* depth = pl.depth[l] + (size_t)f * lv.npix;
+  const uint32_t E = y < h ? csw[(size_t)y * wpr + wc].y : 0u;
+  uint32_t v = (has_vb && y < h) ? tile_valid_word(g, pl, l, f, y, wc, E) : E;
+  // nothing to emit in this tile (half-wave uniform): no depth traffic at all
+  unsigned long long any = __ballot(v != 0u);
+  any = (threadIdx.x & 32) ? (any >> 32) : (any & 0xffffffffull);
+  if (!any) return;
+  // the tile's depths: 8 rows x 128 B per step, whole rows of the tile side by side in LDS
+  float* sd = s_depth[threadIdx.x >> 5];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int rr = 4 * k + (r >> 3), xs = 4 * (r & 7);
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y0 + rr < h && x0 + xs < w) d = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + rr) * w + x0 + xs);  // w is a multiple of 4
+    *reinterpret_cast<float4*>(sd + rr * PT_PITCH + xs) = d;
+  }
+  // (the half-wave reads what it wrote itself: program order within the wave is enough)
+  if (!has_vb) {  // the coarsest level has no validity bits: the depth test of imgpyramidrgbd.cpp:208 on the staged tile
+    uint32_t ok = 0;
+    for (uint32_t m = v; m; m &= m - 1) {
+      const int b = __ffs(m) - 1;
+      if (depth_ok(sd[r * PT_PITCH + b], g.depth_min, g.depth_max)) ok |= 1u << b;
+    }
+    v = ok;
+  }
+  const int cnt = __popc(v);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int u = __shfl_up(incl, o, 32);
+    if (r >= o) incl += u;
+  }
+  const int base = pl.tile_base[(size_t)f * g.total_tiles + tg] + incl - cnt;
+  float4* out = pl.pts_trk[l] + (size_t)f * lv.npix + base;
+  int o = 0;
+  for (uint32_t m = v; m; m &= m - 1, ++o) {
+    const int b = __ffs(m) - 1;
+    const float Z = sd[r * PT_PITCH + b];
+    const float X = __fdiv_rn(Z * ((float)(x0 + b) - lv.cx), lv.fx);
+    const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
+    out[o] = make_float4(X, Y, Z, 1.0f);
+  }
+}
+
 // exclusive scan of a[0..n) by one 1024-thread block; returns the total (valid in every thread).  Per-thread
 // segments, a shuffle scan inside each wave and the 16 wave totals through LDS: two barriers (the Hillis-Steele
 // scan over 1024 LDS entries it replaces took twenty).  s_part: >= 16 ints.
@@ -1431,6 +1585,13 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   bool any = false;
   for (int l = 1; l < g.n_levels; ++l) any = any || g.lv[l].has_orig;
   if (any) hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p);
+}
+
+// the hot path's edge list: tile-ordered, for the tracker (the reference-ordered list is launch_compact, on demand)
+void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_tile_count, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
+  const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
+  hipLaunchKernelGGL(k_pts_tiles, dim3(groups * B), dim3(32 * PT_TILES), 0, s, g, p);
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {

@@ -606,7 +606,8 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
                                                                    TrackParams prm, revo_pair_result* __restrict__ out,
                                                                    EvalOut* __restrict__ eval_out, u64* __restrict__ mail,
                                                                    int n_pairs, int cluster, unsigned epoch_base,
-                                                                   unsigned* seq_ptr, unsigned seq_val, float* prof_out) {
+                                                                   unsigned* seq_ptr, unsigned seq_val, float* prof_out,
+                                                                   unsigned* resident) {
   __shared__ Cand s_cand[2][KMAX];
   __shared__ PassCtl s_pass[2];
   __shared__ LMState s_st[2];
@@ -624,6 +625,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   const int b = blockIdx.x;
   const int pair = (b / (8 * cluster)) * 8 + (b % 8);
   const int member = (b / 8) % cluster;
+  // Residency census (revo_host.hip, "resident gate"): a workgroup that has started holds its CU until it exits, so once
+  // the count reaches the grid size every cluster of this launch is complete and a LATER tracker grid may start filling
+  // the CUs this one frees -- it can no longer keep members of this one off the chip.
+  if (resident && threadIdx.x == 0) __hip_atomic_fetch_add(resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (pair >= n_pairs) return;
   const PairDesc& d = ONE ? one : descs[pair];
   u64* mail_pair = mail + (size_t)pair * 2 * cluster * NVAL;
@@ -1043,6 +1048,17 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   }
 }
 
+// The resident gate: one wave that waits (bounded, sleeping) until the census counter of the tracker launches has
+// reached `want`, i.e. until every workgroup of the previous tracker grid of this device has started.
+__global__ void __launch_bounds__(64) k_track_gate(const unsigned* __restrict__ resident, unsigned want) {
+  if (threadIdx.x != 0) return;
+  for (unsigned spins = 0; spins < 4u * SPIN_LIMIT; ++spins) {
+    const unsigned have = __hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(have - want) >= 0) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 // A.ldlt().solve(b) alone (optimizer.cpp:258-262), for the parity tests of the solver
 __global__ void __launch_bounds__(64) k_solve6(const float* __restrict__ Ab, int n, float* __restrict__ x_out) {
   const int lane = threadIdx.x;
@@ -1093,8 +1109,12 @@ static unsigned next_epoch_base(unsigned* epoch_io, unsigned long long* d_mail, 
   return base;
 }
 
-void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval, int n_pairs,
-                  unsigned long long* d_mail, unsigned* epoch_io, int cluster, hipStream_t s) {
+void launch_track_gate(const unsigned* d_resident, unsigned want, hipStream_t s) {
+  hipLaunchKernelGGL(k_track_gate, dim3(1), dim3(64), 0, s, d_resident, want);
+}
+
+int launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval, int n_pairs,
+                 unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* d_resident, hipStream_t s) {
   static_assert(MAX_TOTAL_EVALS + 64 < TRACK_EPOCH_WINDOW, "epoch window too small");
   const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * NVAL, s);
   const int groups = (n_pairs + 7) / 8;
@@ -1108,7 +1128,8 @@ void launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_res
   prof = g_prof_cap >= n_pairs ? g_prof_dev : nullptr;
 #endif
   hipLaunchKernelGGL(k_track<false>, dim3(groups * 8 * cluster), dim3(TRACK_THREADS), 0, s, PairDesc{}, d_descs, prm, d_out,
-                     d_eval, (u64*)d_mail, n_pairs, cluster, base, (unsigned*)nullptr, 0u, prof);
+                     d_eval, (u64*)d_mail, n_pairs, cluster, base, (unsigned*)nullptr, 0u, prof, d_resident);
+  return groups * 8 * cluster;
 }
 // profile builds: per pair 64 floats of cycle counters of the last batch launch (layout: k_track's s_prof, [63] = passes)
 extern "C" int revo_debug_batch_profile_(float* out, int n_pairs) {
@@ -1123,10 +1144,11 @@ extern "C" int revo_debug_batch_profile_(float* out, int n_pairs) {
 }
 
 // one pair, descriptor by value; out / eval_out may be device-visible pinned host memory
-void launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
-                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,
-                      hipStream_t s) {
+int launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
+                     unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,
+                     unsigned* d_resident, hipStream_t s) {
   const unsigned base = next_epoch_base(epoch_io, d_mail, sizeof(unsigned long long) * 2 * (size_t)cluster * NVAL, s);
   hipLaunchKernelGGL(k_track<true>, dim3(8 * cluster), dim3(TRACK_THREADS), 0, s, desc, (const PairDesc*)nullptr, prm, out,
-                     eval_out, (u64*)d_mail, 1, cluster, base, seq_ptr, seq_val, (float*)nullptr);
+                     eval_out, (u64*)d_mail, 1, cluster, base, seq_ptr, seq_val, (float*)nullptr, d_resident);
+  return 8 * cluster;
 }

@@ -17,6 +17,7 @@ TRACKER_STATE_UNKNOWN = 3
 
 PLANE_GRAY, PLANE_DEPTH, PLANE_EDGES, PLANE_EDGES_ORIG = 0, 1, 2, 3
 PLANE_DT, PLANE_GRADTABLE, PLANE_EDGES3D, PLANE_HIST = 4, 5, 6, 7
+PLANE_EDGES3D_TILED = 8  # the tracker's tile-ordered copy of EDGES3D (what the per-frame build writes)
 
 
 class ImgPyramidSettings(C.Structure):

@@ -62,6 +62,24 @@ def pair640():
     return s, synth.make_pair(3, s)
 
 
+def assert_tiled_list(tag, gp, op, lvl):
+    """The list the build writes for the tracker: the reference's points, bit for bit, ordered by 32x32-pixel tile (raster
+    order of tiles, row-major inside a tile)."""
+    ref = op.read(PLANE_EDGES3D, lvl)
+    til = gp.edges3DTiled(lvl)
+    assert til.shape == ref.shape, "%s: %s vs %s points" % (tag, til.shape, ref.shape)
+    if not len(ref):
+        return
+    K = gp.returnK(lvl).astype(np.float64)
+    x = np.rint(til[:, 0].astype(np.float64) * K[0, 0] / til[:, 2] + K[0, 2]).astype(np.int64)
+    y = np.rint(til[:, 1].astype(np.float64) * K[1, 1] / til[:, 2] + K[1, 2]).astype(np.int64)
+    key = ((y // 32) << 40) | ((x // 32) << 28) | (y << 14) | x
+    assert np.all(np.diff(key) > 0), "%s: not in tile order (or a pixel twice)" % tag
+    # the reference's order is x outer, y inner: re-sorting the tiled list by (x, y) must give the reference's list exactly
+    back = til[np.lexsort((y, x))]
+    assert_same(tag, back, ref)
+
+
 def compare_pyramid(tag, gp, op, s, keyframe):
     for lvl in range(s.nLevels()):
         assert_same("%s_gray%d" % (tag, lvl), gp._read(PLANE_GRAY, lvl), op.read(PLANE_GRAY, lvl))
@@ -71,6 +89,7 @@ def compare_pyramid(tag, gp, op, s, keyframe):
         if s.hist_patch[lvl] > 0:
             assert_same("%s_hist%d" % (tag, lvl), gp._read(PLANE_HIST, lvl), op.read(PLANE_HIST, lvl))
         assert_same("%s_pts%d" % (tag, lvl), gp.return3DEdges(lvl), op.read(PLANE_EDGES3D, lvl))
+        assert_tiled_list("%s_tiled%d" % (tag, lvl), gp, op, lvl)
         if keyframe:
             assert_same("%s_dt%d" % (tag, lvl), gp.returnDistTransform(lvl), op.read(PLANE_DT, lvl))
             assert_same("%s_table%d" % (tag, lvl), gp.returnOptimizationStructure(lvl), op.read(PLANE_GRADTABLE, lvl))
