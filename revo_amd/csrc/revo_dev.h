@@ -30,12 +30,14 @@ struct LevelGeom {
   int edt_block_base;  // first block of this level in the k_edt_rows launch
   int strip_base;      // number of 64-column strips of finer levels (compaction launch decode)
   int cc_base;         // sum of w*nchunk of finer levels
+  int band_rows, nbands, band_base;  // banded hysteresis: rows per band (a multiple of the patch size and of 4), bands, bands of finer levels
 };
 
 struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
   int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
+  int total_bands, any_banded;  // hysteresis bands of all levels; 1 if some level has more than one
   int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
@@ -65,6 +67,8 @@ struct FramePlanes {
   int* npts;                   // [B][REVO_L]
   int* hist_nz;                // [B][REVO_L]
   int* strip_tot;              // [B][total_strips]: edge points per 64-column strip (the compaction's cross-strip offsets)
+  uint32_t* ebits[REVO_L];     // banded hysteresis: the edge bitmap between its kernels (frame stride h*wpr)
+  int* need_full;              // [B][REVO_L]: a band could not label its runs: k_hyst takes the whole (level, frame)
   int* tile_base;              // [B][total_tiles]: first list position of every 32 x 32 tile (exclusive scan per level)
 };
 

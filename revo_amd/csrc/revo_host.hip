@@ -139,10 +139,20 @@ struct revo_batch {
   bool identity_uploaded = false;  // d_descs already holds the identity initial poses (nothing to upload)
   int cluster;
   hipStream_t stream;
+  hipStream_t side = nullptr;                      // the EDT of the keyframes runs here, next to the edge lists
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev0, ev1, ev_upload;
   const revo_pair_result* last_results = nullptr;  // device records of the last track launch (revo_batch_sync decodes their flags)
   revo_pair_result* h_flags = nullptr;             // pinned scratch for that
 };
+
+// experiment knobs (environment): clamped integers, defaults are what ships
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = atoi(e);
+  return v < lo ? lo : (v > hi ? hi : v);
+}
 
 // ---------------------------------------------------------------- geometry --
 static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) {
@@ -166,7 +176,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   if (hi > 0) hi *= hi;
   g->canny_low = (int)std::floor(lo); g->canny_high = (int)std::floor(hi);
   g->use_edge_hist = s.use_edge_hist; g->n_percentage = s.n_percentage;
-  int tile = 0, pix = 0, row = 0, col = 0, cc = 0, tiles32 = 0;
+  int tile = 0, pix = 0, row = 0, col = 0, cc = 0, tiles32 = 0, bands = 0;
   for (int l = 0; l < L; ++l) {
     LevelGeom& v = g->lv[l];
     const float scale = 1.0f / (float)std::pow(2, l);  // camerapyr.h:142
@@ -194,20 +204,26 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     v.strip_base = col; col += (v.w + 63) / 64;
     v.cc_base = cc; cc += v.w * v.nchunk;
     tiles32 += v.wpr * v.nchunk;
+    // banded hysteresis: bands of about 2400 bitmap words, heights a multiple of the histogram patch and of 4 rows
+    {
+      int unit = v.patch > 0 ? v.patch : 4;
+      while (unit % 4) unit *= 2;
+      int rows = (env_int("REVO_HYST_BAND_WORDS", 2400, 64, 1 << 20) / v.wpr) / unit * unit;
+      if (rows < unit) rows = unit;
+      if (rows >= v.h) rows = v.h;
+      v.band_rows = rows;
+      v.nbands = (v.h + rows - 1) / rows;
+      if (v.nbands > 32) { v.band_rows = v.h; v.nbands = 1; }  // (k_hyst_seam holds at most 32 bands' flags)
+      v.band_base = bands; bands += v.nbands;
+      if (v.nbands > 1) g->any_banded = 1;
+    }
   }
   g->total_tiles = tiles32;
+  g->total_bands = bands;
   for (int l = 1; l < L; ++l)  // fillInEdges' gate (imgpyramidrgbd.cpp:188-195 + the patch sizes that exist)
     g->lv[l].has_orig = (s.use_edge_hist && g->lv[l].patch > 0 && g->lv[l - 1].patch > 0) ? 1 : 0;
   g->total_nms_blocks = tile; g->total_pix = pix; g->total_edt_blocks = row; g->total_strips = col; g->total_cc = cc;
   return 0;
-}
-
-// experiment knobs (environment): clamped integers, defaults are what ships
-static int env_int(const char* name, int dflt, int lo, int hi) {
-  const char* e = getenv(name);
-  if (!e || !*e) return dflt;
-  const int v = atoi(e);
-  return v < lo ? lo : (v > hi ? hi : v);
 }
 
 static void build_track_params(const revo_ctx* c, TrackParams* t) {
@@ -345,12 +361,14 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       fs->p.chunk[l] = (int*)take((size_t)v.w * v.nchunk * B * 4);
       fs->p.cmask[l] = (unsigned*)take((size_t)v.w * v.nchunk * B * 4);
       fs->p.vb[l] = (uint8_t*)take((n + 7) / 8);
+      fs->p.ebits[l] = (uint32_t*)take((size_t)v.h * v.wpr * 4 * B);
     }
     fs->own_depth0 = fs->p.depth[0];
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.hist_nz = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.strip_tot = (int*)take(sizeof(int) * (size_t)g.total_strips * B);
     fs->p.tile_base = (int*)take(sizeof(int) * (size_t)g.total_tiles * B);
+    fs->p.need_full = (int*)take(sizeof(int) * REVO_L * B);
     if (with_staging) {
       fs->d_bgr = (uint8_t*)take((size_t)g.lv[0].npix * 3 * B);
       fs->d_depth = (float*)take((size_t)g.lv[0].npix * 4 * B);
@@ -387,8 +405,10 @@ static void frameset_destroy(FrameSet* fs) {
 // borrow_depth (f32 input only): the level-0 depth plane IS the input buffer -- the reference's level 0 is the input
 // image too (imgpyramidrgbd.cpp:62-64), and copying 64 x 1.2 MB per batch was 208 of the 236 MB the first kernel moved.
 // The caller guarantees the buffer stays valid and unchanged for as long as the pyramids are used.
+// with_points = false: stops after fillInEdges; the caller enqueues launch_tile_points itself (batches run it next to the EDT)
 static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
-                          const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false) {
+                          const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false,
+                          bool with_points = true) {
   PyrGeom g = c->geom;
   g.frame0 = 0;
   const int B = fs->B;
@@ -398,8 +418,13 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
   launch_canny_nms(g, fs->p, B, s);
   launch_hyst(g, fs->p, B, s);
   launch_fill(g, fs->p, B, s);
-  launch_tile_points(g, fs->p, B, s);  // the tracker's (tile-ordered) edge list; the reference's order is built on demand
+  if (with_points) launch_tile_points(g, fs->p, B, s);  // the tracker's (tile-ordered) edge list; the reference's order is built on demand
 }
+
+// The tail of a batch build: the edge lists of all frames (two kernels) and the EDT of the keyframes (two kernels) only
+// depend on the edge maps, not on each other, and all four are latency-bound with idle CUs around them: the EDT runs on a
+// side stream next to the lists (fork after fillInEdges, join before the batch's stream goes on).
+static int enqueue_batch_tail(revo_batch* b, hipStream_t s);
 
 // ------------------------------------------------------------------ context --
 static void ctx_free(revo_ctx* c);
@@ -1024,6 +1049,11 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
   HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
+  if (!env_int("REVO_BUILD_NO_FORK", 0, 0, 1)) {
+    HIPCHECK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  }
   b->cluster = pick_cluster(c, n_pairs);
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
@@ -1041,6 +1071,9 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   if (b->stream) hipStreamSynchronize(b->stream);
+  if (b->side) { hipStreamSynchronize(b->side); hipStreamDestroy(b->side); }
+  if (b->ev_fork) hipEventDestroy(b->ev_fork);
+  if (b->ev_join) hipEventDestroy(b->ev_join);
   hipHostFree(b->h_descs); hipHostFree(b->h_flags); hipFree(b->d_descs); hipFree(b->d_mail);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -1052,6 +1085,22 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   ctx_unref(c);
 }
 
+static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
+  const PyrGeom& g = b->ctx->geom;
+  if (b->side) {
+    HIPCHECK(hipEventRecord(b->ev_fork, s));
+    HIPCHECK(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+    launch_keyframe(g, b->fs->p, 0, 2, b->n_pairs, b->side);  // frame 2i = keyframe of pair i
+    HIPCHECK(hipEventRecord(b->ev_join, b->side));
+    launch_tile_points(g, b->fs->p, b->fs->B, s);
+    HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
+  } else {
+    launch_tile_points(g, b->fs->p, b->fs->B, s);
+    launch_keyframe(g, b->fs->p, 0, 2, b->n_pairs, s);
+  }
+  return REVO_OK;
+}
+
 static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, void* stream, bool borrow) {
   if (!b || !d_bgr || !d_depth) return fail(REVO_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(b->ctx->device));
@@ -1060,8 +1109,8 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   // and with the round-2 kernels the step goes from 0.64 ms to 0.73 / 0.84 ms next to a tracker -- the build
   // kernels are throughput-limited, smaller launches only add tails.)
   b->last_results = nullptr;  // records of an earlier launch are the caller's business again
-  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow);
-  launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);  // frame 2i = keyframe of pair i
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false);
+  { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;
@@ -1113,8 +1162,8 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
   b->last_results = nullptr;
-  enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s);
-  launch_keyframe(b->ctx->geom, b->fs->p, 0, 2, b->n_pairs, s);
+  enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false);
+  { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;

@@ -297,6 +297,10 @@ __device__ __forceinline__ void nms_row(const MRow& A, const MRow& B, const MRow
 #endif
 __global__ void __launch_bounds__(256) NMS_OCC k_canny_nms(PyrGeom g, FramePlanes pl) {
   const int f = g.frame0 + blockIdx.z;
+  if (blockIdx.x == 0 && threadIdx.x < REVO_L) {  // per-frame words the banded hysteresis accumulates into / raises
+    pl.need_full[f * REVO_L + threadIdx.x] = 0;
+    pl.hist_nz[f * REVO_L + threadIdx.x] = 0;
+  }
   const int l = level_of(g, blockIdx.x, &LevelGeom::nms_block_base);
   const LevelGeom& lv = g.lv[l];
   const int w = lv.w, h = lv.h;
@@ -421,8 +425,7 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
 #define HA(i)
 #endif
 template <bool C_IN_LDS>
-__global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl) {
-  extern __shared__ uint32_t s_mem[];
+__device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& pl, const int l, const int f, uint32_t* s_mem) {
 #ifdef REVO_HYST_PROFILE
   long long hp[12], ha[8], hlast = 0;
   for (int i = 0; i < 12; ++i) hp[i] = 0;
@@ -433,9 +436,6 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
   // 1-D grid, level-major: workgroup ids go round-robin over the 8 XCDs, and with (level, frame) = (x, z) every
   // level-0 workgroup -- the expensive ones -- had an id that is a multiple of n_levels = 4: all of them on XCDs 0
   // and 4, where a co-running tracker leaves 8 CUs each (200 us per launch instead of 80).  Heaviest level first.
-  const int nB = gridDim.x / g.n_levels;
-  const int l = blockIdx.x / nB;
-  const int f = g.frame0 + blockIdx.x % nB;
   const LevelGeom& lv = g.lv[l];
   const int w = lv.w, h = lv.h, wpr = lv.wpr;
   const int pitch = wpr;                         // one zero row above and below (+ one pad word in front / behind)
@@ -833,6 +833,471 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
            hp[1] - hp[0], hp[5] - hp[1], ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], dbg_runs, dbg_sweeps, dbg_bands, (int)done);
 #endif
 }
+// n_items = levels x frames of the launch.  only_flagged = 0: one workgroup per (level, frame), level-major (workgroup ids go
+// round-robin over the 8 XCDs: with (level, frame) = (x, z) every level-0 workgroup -- the expensive ones -- had an id that is
+// a multiple of n_levels = 4, i.e. all of them sat on XCDs 0 and 4).  only_flagged = 1 (launch D of the banded path): a few
+// workgroups share the (level, frame) pairs a band handed over -- normally none, and then the launch costs a flag sweep.
+template <bool C_IN_LDS>
+__global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl, int only_flagged, int n_frames) {
+  extern __shared__ uint32_t s_mem[];
+  const int n_items = g.n_levels * n_frames;
+  if (only_flagged) {  // one parallel sweep over the flags: normally nothing is flagged and the launch ends here
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    for (int item = threadIdx.x; item < n_items; item += HYST_THREADS)
+      if (pl.need_full[(g.frame0 + item % n_frames) * REVO_L + item / n_frames]) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;
+  }
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int l = item / n_frames;
+    const int f = g.frame0 + item % n_frames;
+    if (only_flagged && !pl.need_full[f * REVO_L + l]) continue;
+    hyst_level<C_IN_LDS>(g, pl, l, f, s_mem);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a5 (second half), BANDED: the same hysteresis with several workgroups per (level, frame).
+// One 1024-thread workgroup per (level, frame) made the launch as long as its heaviest frame (80 us for ~10 000 weak runs
+// at 640x480, on 64 of 256 CUs), and a level whose bitmaps + union-find tables do not fit one CU's LDS (1280x960) fell
+// back to flood filling.  Now a level is cut into bands of rows; cv::Canny's result is reached exactly in three steps:
+//   A  k_hyst_band : per band, the union-find over the band's weak runs (as in k_hyst), seeded by the band's strong pixels
+//                    AND the strong pixels of the two neighbouring rows; locally anchored components are promoted; the band
+//                    leaves its edge bitmap, every run's root, the run records and one flag bit per root in HBM scratch
+//   S  k_hyst_seam : per (level, frame), one small workgroup walks the seams: a weak run in the last row of a band and a
+//                    weak run in the first row of the next that touch (8-neighbourhood) belong to one component, so their
+//                    roots must end with the same flag; flags are OR-ed across touching runs until nothing changes (the
+//                    fixpoint is the connectivity closure over all seams, whatever zig-zag a component takes)
+//   P  k_hyst_out  : per band, runs whose root got its flag from the other side of a seam are promoted, then edgesPyr
+//                    (+ edgesOrigPyr), the edge bitmap (cs[].y) and the band's histogram tiles are written from LDS
+// A band whose runs exceed its label space marks the (level, frame) for k_hyst, which then runs for that pair alone
+// (launch D: every other workgroup of it exits at once).
+// ---------------------------------------------------------------------------
+#ifndef HB_THREADS
+#define HB_THREADS 1024
+#endif
+#ifndef HB_LDS_WORDS
+#define HB_LDS_WORDS 16384   // 64 KB per band workgroup: two per CU
+#endif
+struct BandRef { int l, R0, R1; };
+__device__ __forceinline__ BandRef band_ref(const PyrGeom& g, int bi) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < REVO_L; ++k)
+    if (k < g.n_levels && bi >= g.lv[k].band_base) l = k;
+  const LevelGeom& lv = g.lv[l];
+  const int b = bi - lv.band_base;
+  BandRef r;
+  r.l = l; r.R0 = b * lv.band_rows; r.R1 = min(lv.h, r.R0 + lv.band_rows);
+  return r;
+}
+// persistent record of a band in pl.scratch[l] (ints), at the band's own pixels: f * npix + R0 * w
+//   [0] runs, [1] set by S: some root of this band got its flag across a seam, [2] 1 = the band's union-find is valid
+//   [4 .. 4+wpr)        runs before word c of the band's FIRST row          [4+wpr .. 4+2wpr) ... of its LAST row
+//   then capb/32 words of root flags, capb/2 words of 16-bit roots (one per run), capb run records
+// runs a band may label: ONE value per level (every band's record has the same layout): what a full band's tables hold in
+// LDS, 16-bit ids, and what fits the smallest (= last) band's share of the scratch plane
+__device__ __forceinline__ int band_capb(const LevelGeom& lv) {
+  const int hb = lv.band_rows, nwb = hb * lv.wpr;
+  const int table_words = HB_LDS_WORDS - (nwb + (nwb + 2) / 2);
+  const int e_words = (hb + 2) * lv.wpr + 2;
+  int cap = min(table_words / 2, table_words - e_words);
+  cap = min(cap, 65535);
+  const int h_last = lv.h - (lv.nbands - 1) * lv.band_rows;
+  cap = min(cap, ((h_last * lv.w - 4 - 2 * lv.wpr) / 8) * 5);
+  return max(cap, 0) & ~31;
+}
+struct BandRec { int* hdr; int* bs_first; int* bs_last; uint32_t* flags; unsigned short* root; uint32_t* rec; };
+__device__ __forceinline__ BandRec band_rec(const FramePlanes& pl, const LevelGeom& lv, int l, int f, int R0, int capb) {
+  int* base = pl.scratch[l] + (size_t)f * lv.npix + (size_t)R0 * lv.w;
+  BandRec r;
+  r.hdr = base; r.bs_first = base + 4; r.bs_last = base + 4 + lv.wpr;
+  r.flags = reinterpret_cast<uint32_t*>(base + 4 + 2 * lv.wpr);
+  r.root = reinterpret_cast<unsigned short*>(base + 4 + 2 * lv.wpr + capb / 32);
+  r.rec = reinterpret_cast<uint32_t*>(base + 4 + 2 * lv.wpr + capb / 32 + capb / 2);
+  return r;
+}
+
+__global__ void __launch_bounds__(HB_THREADS) k_hyst_band(PyrGeom g, FramePlanes pl) {
+  extern __shared__ uint32_t s_mem[];
+  __shared__ int s_wsum[HB_THREADS / 64];
+  __shared__ int s_total;
+  // 1-D grid, band-major (level 0's bands first): consecutive ids = the same band of consecutive frames
+  const int nB = gridDim.x / g.total_bands;
+  const BandRef br = band_ref(g, blockIdx.x / nB);
+  const int f = g.frame0 + blockIdx.x % nB;
+  const int l = br.l;
+  const LevelGeom& lv = g.lv[l];
+  const int h = lv.h, wpr = lv.wpr, pitch = wpr;
+  const int hb = br.R1 - br.R0, nwb = hb * wpr, e_words = (hb + 2) * pitch + 2;
+  const int tid = threadIdx.x;
+  uint32_t* Cl = s_mem;
+  uint32_t* Ebase = s_mem + (HB_LDS_WORDS - e_words);
+  uint32_t* E = Ebase + 1;  // E[(r + 1) * pitch + c] = E(R0 + r, c), r = -1 .. hb: rows -1 and hb hold the neighbours' STRONG pixels
+  const uint2* cs = pl.cs[l] + ((size_t)f * h + br.R0) * wpr;  // the band's first row
+  const int capb = band_capb(lv);
+  const BandRec rec_out = band_rec(pl, lv, l, f, br.R0, capb);
+  auto load_e = [&](bool with_cl) {  // E = S (+ the halo rows) [, Cl = C & ~S]; with_cl = false: E = S | (C & ~Cl) (rebuild)
+    if (tid == 0) { Ebase[0] = 0u; Ebase[e_words - 1] = 0u; }
+    for (int c = tid; c < wpr; c += HB_THREADS) {
+      E[c] = br.R0 > 0 ? cs[c - wpr].y : 0u;                        // row R0 - 1
+      E[(hb + 1) * pitch + c] = br.R1 < h ? cs[nwb + c].y : 0u;     // row R1
+    }
+    for (int i0 = tid; i0 < nwb; i0 += 4 * HB_THREADS) {  // four loads in flight
+      uint2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = cs[min(i0 + k * HB_THREADS, nwb - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * HB_THREADS;
+        if (i < nwb) {
+          if (with_cl) { E[pitch + i] = v[k].y; Cl[i] = v[k].x & ~v[k].y; }
+          else E[pitch + i] = v[k].y | (v[k].x & ~Cl[i]);
+        }
+      }
+    }
+  };
+  load_e(true);
+  __syncthreads();
+  unsigned short* Bs = reinterpret_cast<unsigned short*>(Cl + nwb);  // runs before word i (nwb + 1 entries)
+  uint32_t* parent = Cl + nwb + (nwb + 2) / 2;
+  const int table_words = HB_LDS_WORDS - (nwb + (nwb + 2) / 2);
+  const int cap_keep = (table_words - e_words) / 2;  // up to here the tables end below E
+  auto starts = [](uint32_t wk) -> uint32_t { return wk & ~(wk << 1); };
+  const float inv_wpr = 1.0f / (float)wpr;
+  const uint32_t FLAG = 0x80000000u, IDM = 0x7fffffffu;
+  // ids: exclusive prefix of the run counts
+  {
+    const int wpt = (nwb + HB_THREADS - 1) / HB_THREADS;
+    const int w0 = min(nwb, tid * wpt), w1 = min(nwb, w0 + wpt);
+    int mine = 0;
+    for (int wi = w0; wi < w1; ++wi) mine += __popc(starts(Cl[wi]));
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int k = 0; k < (tid >> 6); ++k) before += s_wsum[k];
+    if (tid == HB_THREADS - 1) { s_total = before + mine; Bs[nwb] = (unsigned short)min(65535, before + mine); }
+    for (int wi = w0; wi < w1; ++wi) {
+      Bs[wi] = (unsigned short)before;
+      before += __popc(starts(Cl[wi]));
+    }
+    __syncthreads();
+  }
+  const int nr = s_total;
+  if (nr > capb) {  // beyond this band's label space: k_hyst takes the whole (level, frame)
+    if (tid == 0) { pl.need_full[f * REVO_L + l] = 1; rec_out.hdr[0] = 0; rec_out.hdr[1] = 0; rec_out.hdr[2] = 0; }
+    return;
+  }
+  uint32_t* rec = parent + nr;  // run -> word << 10 | first bit << 5 | length - 1
+  if (nr > 0) {
+    auto id_of = [&](int wi, int bit) -> int { return (int)Bs[wi] + __popc(starts(Cl[wi]) & ((2u << bit) - 1u)) - 1; };
+    auto key_of = [](int x) -> uint32_t { return ((((uint32_t)x * 40503u) >> 1) & 0x7fffu) << 16 | (uint32_t)x; };
+    auto find = [&](int x) -> int {
+      uint32_t p2 = parent[x] & IDM;
+      while ((int)(p2 & 0xffffu) != x) {
+        const uint32_t gp = parent[p2 & 0xffffu] & IDM;
+        if (gp != p2) atomicMin(&parent[x], gp);
+        x = (int)(p2 & 0xffffu); p2 = gp;
+      }
+      return x;
+    };
+    auto unite = [&](int a2, int b2) {
+      for (;;) {
+        a2 = find(a2); b2 = find(b2);
+        if (a2 == b2) return;
+        uint32_t ka = key_of(a2), kb = key_of(b2);
+        if (ka > kb) { const int t2 = a2; a2 = b2; b2 = t2; const uint32_t t3 = ka; ka = kb; kb = t3; }
+        const uint32_t old = atomicMin(&parent[b2], ka);
+        if (old == kb) return;
+        b2 = (int)(old & 0xffffu);
+      }
+    };
+    for (int wi = tid; wi < nwb; wi += HB_THREADS) {
+      int me = (int)Bs[wi];
+      const uint32_t wk = Cl[wi];
+      for (uint32_t m = starts(wk); m; m &= m - 1, ++me) {
+        const int bit = __ffs(m) - 1;
+        const uint32_t t2 = ~(wk >> bit);
+        const int len = t2 ? __ffs(t2) - 1 : 32 - bit;
+        parent[me] = key_of(me);
+        rec[me] = ((uint32_t)wi << 10) | ((uint32_t)bit << 5) | (uint32_t)(len - 1);
+      }
+    }
+    __syncthreads();
+    // links: the run continuing from the previous word; the touching runs of the row above (inside the band)
+    for (int me = tid; me < nr; me += HB_THREADS) {
+      const uint32_t rc = rec[me];
+      const int wi = (int)(rc >> 10);
+      const uint32_t run = (0xffffffffu >> (31u - (rc & 31u))) << ((rc >> 5) & 31u);
+      int r = (int)(((float)wi + 0.5f) * inv_wpr);
+      r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
+      const int c = wi - r * wpr;
+      if ((run & 1u) && c > 0 && (Cl[wi - 1] >> 31)) unite(me, id_of(wi - 1, 31));
+      if (r == 0) continue;
+      for (uint32_t a2 = Cl[wi - wpr] & (run | (run << 1) | (run >> 1)); a2;) {
+        const int ab = __ffs(a2) - 1;
+        a2 &= ~(a2 & ~(a2 + (1u << ab)));
+        unite(me, id_of(wi - wpr, ab));
+      }
+      if ((run & 1u) && c > 0 && (Cl[wi - wpr - 1] >> 31)) unite(me, id_of(wi - wpr - 1, 31));
+      if ((run >> 31) && c < wpr - 1 && (Cl[wi - wpr + 1] & 1u)) unite(me, id_of(wi - wpr + 1, 0));
+    }
+    __syncthreads();
+    for (int me = tid; me < nr; me += HB_THREADS) {
+      parent[me] = key_of(find(me));   // every run straight under its root
+      rec_out.rec[me] = rec[me];       // (the records go to the band's record NOW: they may lie where E is rebuilt)
+    }
+    __syncthreads();
+    if (nr > cap_keep) {  // the tables grew over E: rebuild it
+      load_e(false);
+      __syncthreads();
+    }
+    // components that touch an edge pixel (strong, in the band or in the neighbouring rows): flag the root
+    for (int wi = tid; wi < nwb; wi += HB_THREADS) {
+      const uint32_t wk = Cl[wi];
+      if (!wk) continue;
+      int r = (int)(((float)wi + 0.5f) * inv_wpr);
+      r += (r + 1) * wpr <= wi ? 1 : (r * wpr > wi ? -1 : 0);
+      const int c = wi - r * wpr;
+      const uint32_t lm = c > 0 ? ~0u : 0u, rm = c < wpr - 1 ? ~0u : 0u;
+      const uint32_t* Xc = E + pitch + wi;
+      const uint32_t sd = dil3(Xc[-pitch], Xc[-pitch - 1] & lm, Xc[-pitch + 1] & rm) | dil3(Xc[pitch], Xc[pitch - 1] & lm, Xc[pitch + 1] & rm) |
+                          __builtin_amdgcn_alignbit(Xc[0], Xc[-1] & lm, 31) | __builtin_amdgcn_alignbit(Xc[1] & rm, Xc[0], 1);
+      if (!(wk & sd)) continue;
+      const uint32_t touched = run_fill(wk, wk & sd);
+      int me = (int)Bs[wi];
+      for (uint32_t m = starts(wk); m; m &= m - 1, ++me)
+        if (touched & m & (0u - m)) {
+          uint32_t* root = &parent[parent[me] & 0xffffu];
+          if (!(*root & FLAG)) atomicOr(root, FLAG);
+        }
+    }
+    __syncthreads();
+    // a weak run is an edge iff its root is flagged
+    for (int wi = tid; wi < nwb; wi += HB_THREADS) {
+      const uint32_t wk = Cl[wi];
+      if (!wk) continue;
+      int me = (int)Bs[wi];
+      uint32_t prom = 0;
+      for (uint32_t m = starts(wk); m; m &= m - 1, ++me)
+        if (parent[parent[me] & 0xffffu] & FLAG) prom |= m & (0u - m);
+      if (prom) E[pitch + wi] |= run_fill(wk, prom);  // (Cl keeps the run: its id must stay what the records say)
+    }
+    __syncthreads();
+  }
+  // ---- the band's record: edge bitmap, run count, boundary-row id bases, root of every run, run records, root flags
+  uint32_t* eb = pl.ebits[l] + ((size_t)f * h + br.R0) * wpr;
+  for (int i = tid; i < nwb; i += HB_THREADS) eb[i] = E[pitch + i];
+  if (tid == 0) { rec_out.hdr[0] = nr; rec_out.hdr[1] = 0; rec_out.hdr[2] = 1; }
+  for (int c = tid; c < wpr; c += HB_THREADS) { rec_out.bs_first[c] = Bs[c]; rec_out.bs_last[c] = Bs[(hb - 1) * wpr + c]; }
+  for (int i = tid; i < (nr + 31) / 32; i += HB_THREADS) {
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; ++k) {
+      const int me = 32 * i + k;
+      if (me < nr && (int)(parent[me] & 0xffffu) == me && (parent[me] & FLAG)) bits |= 1u << k;
+    }
+    rec_out.flags[i] = bits;
+  }
+  for (int me = tid; me < nr; me += HB_THREADS) rec_out.root[me] = (unsigned short)(parent[me] & 0xffffu);
+}
+
+// S: flags across the seams of one (level, frame).  One sweep over the seams lists the touching (run above, run below) pairs
+// as (band, root above, root below) in LDS -- the only part that reads HBM --, then the flags are OR-ed along the pairs
+// until nothing changes.
+#define HS_THREADS 256
+#define HS_MAX_BANDS 32
+#define HS_MAX_PAIRS 6144
+__global__ void __launch_bounds__(HS_THREADS) k_hyst_seam(PyrGeom g, FramePlanes pl) {
+  extern __shared__ uint32_t s_fl[];  // the bands' root flags, back to back (capb / 32 words per band)
+  __shared__ uint2 s_pair[HS_MAX_PAIRS];
+  __shared__ int s_npairs;
+  __shared__ int s_changed_band[HS_MAX_BANDS];
+  const int nB = gridDim.x / g.n_levels;
+  const int l = blockIdx.x / nB;
+  const int f = g.frame0 + blockIdx.x % nB;
+  const LevelGeom& lv = g.lv[l];
+  const int nb = lv.nbands;
+  if (nb <= 1 || pl.need_full[f * REVO_L + l]) return;
+  const int wpr = lv.wpr, h = lv.h;
+  const int tid = threadIdx.x;
+  const int capb = band_capb(lv), fw = capb / 32;
+  const uint2* cs = pl.cs[l] + (size_t)f * h * wpr;
+  for (int b = 0; b < nb; ++b) {
+    const BandRec rb = band_rec(pl, lv, l, f, b * lv.band_rows, capb);
+    const int n = (rb.hdr[0] + 31) / 32;
+    for (int i = tid; i < fw; i += HS_THREADS) s_fl[b * fw + i] = i < n ? rb.flags[i] : 0u;
+  }
+  if (tid < HS_MAX_BANDS) s_changed_band[tid] = 0;
+  if (tid == 0) s_npairs = 0;
+  __syncthreads();
+  auto starts = [](uint32_t wk) -> uint32_t { return wk & ~(wk << 1); };
+  auto weak_at = [&](int y, int c) -> uint32_t { if (c < 0 || c >= wpr) return 0u; const uint2 v = cs[(size_t)y * wpr + c]; return v.x & ~v.y; };
+  for (int item = tid; item < (nb - 1) * wpr; item += HS_THREADS) {
+    const int sm = item / wpr, c = item - sm * wpr;
+    const int yb = (sm + 1) * lv.band_rows, ya = yb - 1;      // last row of band sm, first row of band sm + 1
+    const uint32_t Wa = weak_at(ya, c);
+    const uint32_t Wl = weak_at(yb, c - 1), Wm = weak_at(yb, c), Wr = weak_at(yb, c + 1);
+    if (!Wa || !(Wm | (Wl >> 31) | (Wr & 1u))) continue;
+    const BandRec ra = band_rec(pl, lv, l, f, sm * lv.band_rows, capb);
+    const BandRec rbb = band_rec(pl, lv, l, f, yb, capb);
+    int ida = ra.bs_last[c];
+    const int idm = rbb.bs_first[c], idl = c > 0 ? rbb.bs_first[c - 1] : 0, idr = c < wpr - 1 ? rbb.bs_first[c + 1] : 0;
+    for (uint32_t m = starts(Wa); m; m &= m - 1, ++ida) {
+      const int bit = __ffs(m) - 1;
+      const uint32_t t2 = ~(Wa >> bit);
+      const int len = t2 ? __ffs(t2) - 1 : 32 - bit;
+      const uint32_t ma = (0xffffffffu >> (32 - len)) << bit;
+      int roota = -1;
+      // the runs of row yb this run touches: in its own word column, and the neighbours' last / first pixel
+      for (int side = 0; side < 3; ++side) {
+        int idb0; uint32_t Wb, hits;
+        if (side == 0) { Wb = Wm; hits = Wm & (ma | (ma << 1) | (ma >> 1)); idb0 = idm; }
+        else if (side == 1) { Wb = Wl; hits = (ma & 1u) ? (Wl & 0x80000000u) : 0u; idb0 = idl; }
+        else { Wb = Wr; hits = (ma >> 31) ? (Wr & 1u) : 0u; idb0 = idr; }
+        while (hits) {
+          const int hb2 = __ffs(hits) - 1;
+          const uint32_t upto = (2u << hb2) - 1u;                      // pixels 0 .. hb2
+          const int k = __popc(starts(Wb) & upto) - 1;                 // index of the run that holds pixel hb2
+          const uint32_t gap = ~Wb & upto;                             // holes up to hb2
+          const int first = gap ? 32 - __clz(gap) : 0;                 // first pixel of that run
+          const uint32_t t3 = ~(Wb >> first);
+          const int lenb = t3 ? __ffs(t3) - 1 : 32 - first;
+          hits &= ~((0xffffffffu >> (32 - lenb)) << first);
+          if (roota < 0) roota = ra.root[ida];
+          const int rootb = rbb.root[idb0 + k];
+          const int slot = atomicAdd(&s_npairs, 1);
+          if (slot < HS_MAX_PAIRS) s_pair[slot] = make_uint2((uint32_t)sm, (uint32_t)roota | ((uint32_t)rootb << 16));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int np = s_npairs;
+  if (np > HS_MAX_PAIRS) {  // (a seam with thousands of weak contacts: noise) -- k_hyst takes the whole (level, frame)
+    if (tid == 0) pl.need_full[f * REVO_L + l] = 1;
+    return;
+  }
+  for (int it = 0; it < 65536; ++it) {
+    bool changed = false;
+    for (int i = tid; i < np; i += HS_THREADS) {
+      const uint2 pr = s_pair[i];
+      const int sm = (int)pr.x, roota = (int)(pr.y & 0xffffu), rootb = (int)(pr.y >> 16);
+      uint32_t* fa = s_fl + sm * fw;
+      uint32_t* fb = s_fl + (sm + 1) * fw;
+      const bool A = (fa[roota >> 5] >> (roota & 31)) & 1u, Bf = (fb[rootb >> 5] >> (rootb & 31)) & 1u;
+      if (A != Bf) {
+        if (!A) { atomicOr(&fa[roota >> 5], 1u << (roota & 31)); s_changed_band[sm] = 1; }
+        else { atomicOr(&fb[rootb >> 5], 1u << (rootb & 31)); s_changed_band[sm + 1] = 1; }
+        changed = true;
+      }
+    }
+    if (!__syncthreads_or(changed ? 1 : 0)) break;
+  }
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    if (!s_changed_band[b]) continue;
+    const BandRec rb = band_rec(pl, lv, l, f, b * lv.band_rows, capb);
+    const int n = (rb.hdr[0] + 31) / 32;
+    for (int i = tid; i < n; i += HS_THREADS) rb.flags[i] = s_fl[b * fw + i];
+    if (tid == 0) rb.hdr[1] = 1;
+  }
+}
+
+// P: promotions that came across a seam, then the band's outputs
+#define HO_THREADS 512
+__global__ void __launch_bounds__(HO_THREADS) k_hyst_out(PyrGeom g, FramePlanes pl) {
+  extern __shared__ uint32_t s_mem[];
+  const int nB = gridDim.x / g.total_bands;
+  const BandRef br = band_ref(g, blockIdx.x / nB);
+  const int f = g.frame0 + blockIdx.x % nB;
+  const int l = br.l;
+  if (pl.need_full[f * REVO_L + l]) return;
+  const LevelGeom& lv = g.lv[l];
+  const int w = lv.w, h = lv.h, wpr = lv.wpr, pitch = wpr;
+  const int hb = br.R1 - br.R0, nwb = hb * wpr;
+  const int tid = threadIdx.x;
+  uint32_t* E = s_mem;                    // E[r * pitch + c], r = 0 .. hb - 1 (the band's own rows)
+  uint32_t* eb = pl.ebits[l] + ((size_t)f * h + br.R0) * wpr;
+  for (int i = tid; i < nwb; i += HO_THREADS) E[i] = eb[i];
+  const BandRec rb = band_rec(pl, lv, l, f, br.R0, band_capb(lv));
+  const bool promote = rb.hdr[1] != 0;
+  __syncthreads();
+  if (promote) {
+    const int nr = rb.hdr[0];
+    for (int me = tid; me < nr; me += HO_THREADS) {
+      const int root = rb.root[me];
+      if ((rb.flags[root >> 5] >> (root & 31)) & 1u) {
+        const uint32_t rc = rb.rec[me];
+        atomicOr(&E[rc >> 10], (0xffffffffu >> (31u - (rc & 31u))) << ((rc >> 5) & 31u));
+      }
+    }
+    __syncthreads();
+  }
+  // edgesPyr / edgesOrigPyr: 16 pixels per store (band heights are multiples of 4 rows, widths of 4 pixels)
+  uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix + (size_t)br.R0 * w;
+  uint8_t* orig = lv.has_orig ? pl.edges_orig[l] + (size_t)f * lv.npix + (size_t)br.R0 * w : nullptr;
+  const bool rows16 = (w & 15) == 0;
+  const float inv_w = 1.0f / (float)w;
+  for (int i = tid; i < hb * w / 16; i += HO_THREADS) {
+    const int p = i * 16;
+    int y = (int)(((float)p + 0.5f) * inv_w);
+    y += (y + 1) * w <= p ? 1 : (y * w > p ? -1 : 0);
+    const int x = p - y * w;
+    uint32_t o[4];
+    if (rows16) {
+      const uint32_t bits = (E[y * pitch + (x >> 5)] >> (x & 31)) & 0xffffu;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = ((((bits >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int xx = x + 4 * q, yy = y;
+        while (xx >= w) { xx -= w; yy += 1; }
+        const uint32_t bits = (E[yy * pitch + (xx >> 5)] >> (xx & 31)) & 0xfu;
+        o[q] = ((bits * 0x00204081u) & 0x01010101u) * 0xffu;
+      }
+    }
+    const uint4 v = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(edges + p) = v;
+    if (orig) *reinterpret_cast<uint4*>(orig + p) = v;
+  }
+  {
+    uint2* csw = pl.cs[l] + ((size_t)f * h + br.R0) * wpr;
+    for (int i = tid; i < nwb; i += HO_THREADS) csw[i].y = E[i];
+  }
+  // the band's histogram tiles (band heights are multiples of the patch size; imgpyramidrgbd.cpp:146-172)
+  if (lv.patch > 0) {
+    const int ty0 = br.R0 / lv.patch, ty1 = min(lv.hist_h, br.R1 / lv.patch);
+    const int ntiles = max(0, ty1 - ty0) * lv.hist_w;
+    int nz = 0;
+    for (int t = tid; t < ntiles; t += HO_THREADS) {
+      const int ty = ty0 + t / lv.hist_w, tx = t % lv.hist_w;
+      const int xa = tx * lv.patch, xb = xa + lv.patch;
+      const int wa = xa >> 5, wb = (xb - 1) >> 5;
+      const uint32_t ma = ~0u << (xa & 31), mb = (xb & 31) ? ~0u >> (32 - (xb & 31)) : ~0u;
+      const uint32_t m0 = wa == wb ? ma & mb : ma, m1 = wb > wa + 1 ? ~0u : (wb > wa ? mb : 0u), m2 = wb > wa + 1 ? mb : 0u;
+      const int o1 = wb > wa ? 1 : 0, o2 = wb > wa + 1 ? 2 : 0;
+      const uint32_t* row = E + (ty * lv.patch - br.R0) * pitch + wa;
+      int cnt = 0;
+      for (int y = 0; y < lv.patch; ++y, row += pitch) cnt += __popc(row[0] & m0) + __popc(row[o1] & m1) + __popc(row[o2] & m2);
+      const uint8_t v = (uint8_t)(cnt & 255);
+      pl.hist[l][(size_t)f * lv.hist_w * lv.hist_h + (size_t)ty * lv.hist_w + tx] = v;
+      nz += v != 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o);
+    if ((tid & 63) == 0 && nz) atomicAdd(&pl.hist_nz[f * REVO_L + l], nz);  // (zeroed by k_canny_nms)
+  }
+}
 
 // a7: fillInEdges (imgpyramidrgbd.cpp:111-145, gate 188-195).  Level l reads
 // the already-filled level l-1, so one 1024-thread block per frame walks the
@@ -1125,23 +1590,32 @@ __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) 
   for (int i = tid; i < ntiles; i += 1024) s_tile[i] = 0;
   __syncthreads();
   // half-waves take tiles round-robin; lane r = row r of the tile
-  for (int t = tid >> 5; t < ntiles; t += 32) {
-    const int c = t / wpr, wc = t - c * wpr;
-    const int y = c * 32 + r;
-    uint32_t v = 0;
-    if (y < h) {
-      const uint32_t E = csw[(size_t)y * wpr + wc].y;
-      if (has_vb) v = tile_valid_word(g, pl, l, f, y, wc, E);
-      else
-        for (uint32_t m = E; m; m &= m - 1) {  // the coarsest level: a few thousand pixels per frame
-          const int b = __ffs(m) - 1;
-          if (depth_ok(depth[(size_t)y * lv.w + 32 * wc + b], g.depth_min, g.depth_max)) v |= 1u << b;
-        }
-    }
-    int cnt = __popc(v);
+  // (four tiles per trip: their loads are independent, a half-wave waits for memory once per trip)
+  for (int t0 = tid >> 5; t0 < ntiles; t0 += 4 * 32) {
+    uint32_t v[4];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 32);
-    if (r == 0) s_tile[t] = cnt;
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + 32 * q;
+      const int c = t / wpr, wc = t - c * wpr;
+      const int y = c * 32 + r;
+      v[q] = 0;
+      if (t < ntiles && y < h) {
+        const uint32_t E = csw[(size_t)y * wpr + wc].y;
+        if (has_vb) v[q] = tile_valid_word(g, pl, l, f, y, wc, E);
+        else
+          for (uint32_t m = E; m; m &= m - 1) {  // the coarsest level: a few thousand pixels per frame
+            const int b = __ffs(m) - 1;
+            if (depth_ok(depth[(size_t)y * lv.w + 32 * wc + b], g.depth_min, g.depth_max)) v[q] |= 1u << b;
+          }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int cnt = __popc(v[q]);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 32);
+      if (r == 0 && t0 + 32 * q < ntiles) s_tile[t0 + 32 * q] = cnt;
+    }
   }
   __syncthreads();
   // exclusive scan over the level's tiles (<= 2 per thread)
@@ -1165,6 +1639,7 @@ __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) 
   if (tid == 0) pl.npts[f * REVO_L + l] = total;
 }
 
+#ifdef PT_OLD
 #define PT_TILES 8                 // tiles (half-waves) per block of k_pts_tiles
 #define PT_PITCH 36                // floats per staged depth row (16-byte aligned rows, banks spread)
 __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
@@ -1232,6 +1707,90 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
   }
 }
 
+#else
+#define PT_TILES 8                 // tiles (half-waves) per block of k_pts_tiles
+#define PT_PITCH 36                // floats per staged depth row (16-byte aligned rows, banks spread)
+__global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
+  __shared__ float s_depth[PT_TILES][32 * PT_PITCH];
+  __shared__ unsigned short s_src[PT_TILES][1024];  // list position inside the tile -> (row << 5 | column)
+  // 1-D grid, frame fastest (the tile groups of a frame share one XCD's L2)
+  const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
+  const int nB = gridDim.x / groups;
+  const int f = g.frame0 + blockIdx.x % nB;
+  const int tg = (blockIdx.x / nB) * PT_TILES + (threadIdx.x >> 5);
+  if (tg >= g.total_tiles) return;
+  int l = 0, t = tg;
+  for (int k = 0; k < g.n_levels; ++k) {
+    const int n = g.lv[k].wpr * g.lv[k].nchunk;
+    if (t < n) { l = k; break; }
+    t -= n;
+  }
+  const LevelGeom& lv = g.lv[l];
+  const int wpr = lv.wpr, h = lv.h, w = lv.w;
+  const int c = t / wpr, wc = t - c * wpr;
+  const int r = threadIdx.x & 31;
+  const int y0 = c * 32, x0 = wc * 32, y = y0 + r;
+  const bool has_vb = l < g.n_levels - 1;
+  const uint2* csw = pl.cs[l] + (size_t)f * h * wpr;
+  const float* depth = pl.depth[l] + (size_t)f * lv.npix;
+  const int tile_first = pl.tile_base[(size_t)f * g.total_tiles + tg];  // (requested early: needed last)
+  const uint32_t E = y < h ? csw[(size_t)y * wpr + wc].y : 0u;
+  uint32_t v = (has_vb && y < h) ? tile_valid_word(g, pl, l, f, y, wc, E) : E;
+  // nothing to emit in this tile (half-wave uniform): no depth traffic at all
+  unsigned long long any = __ballot(v != 0u);
+  any = (threadIdx.x & 32) ? (any >> 32) : (any & 0xffffffffull);
+  if (!any) return;
+  // the tile's depths: 8 rows x 128 B per step, whole rows of the tile side by side in LDS
+  float* sd = s_depth[threadIdx.x >> 5];
+  {
+    float4 d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int rr = 4 * k + (r >> 3), xs = 4 * (r & 7);
+      d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y0 + rr < h && x0 + xs < w) d[k] = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + rr) * w + x0 + xs);  // w is a multiple of 4
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(sd + (4 * k + (r >> 3)) * PT_PITCH + 4 * (r & 7)) = d[k];
+  }
+  // (the half-wave reads what it wrote itself: program order within the wave is enough)
+  if (!has_vb) {  // the coarsest level has no validity bits: the depth test of imgpyramidrgbd.cpp:208 on the staged tile
+    uint32_t ok = 0;
+    for (uint32_t m = v; m; m &= m - 1) {
+      const int b = __ffs(m) - 1;
+      if (depth_ok(sd[r * PT_PITCH + b], g.depth_min, g.depth_max)) ok |= 1u << b;
+    }
+    v = ok;
+  }
+  const int cnt = __popc(v);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int u = __shfl_up(incl, o, 32);
+    if (r >= o) incl += u;
+  }
+  const int total = __shfl(incl, 31, 32);
+  // Row r's points sit at positions incl - cnt .. incl - 1 of the tile.  A row of a horizontal edge holds up to 32 of them,
+  // a row crossed by a vertical edge one: each lane only records WHERE its points are (a few instructions per point) ...
+  unsigned short* src = s_src[threadIdx.x >> 5];
+  {
+    int o = incl - cnt;
+    for (uint32_t m = v; m; m &= m - 1, ++o) src[o] = (unsigned short)((r << 5) | (__ffs(m) - 1));
+  }
+  // ... and the back-projection (two correctly rounded divisions per point) and the stores are dealt out evenly: lane k takes
+  // positions k, k + 32, ...: consecutive lanes write consecutive 16-byte entries
+  float4* out = pl.pts_trk[l] + (size_t)f * lv.npix + tile_first;
+  for (int k = r; k < total; k += 32) {
+    const int rb = src[k];
+    const int rr = rb >> 5, b = rb & 31;
+    const float Z = sd[rr * PT_PITCH + b];
+    const float X = __fdiv_rn(Z * ((float)(x0 + b) - lv.cx), lv.fx);
+    const float Y = __fdiv_rn(Z * ((float)(y0 + rr) - lv.cy), lv.fy);
+    out[k] = make_float4(X, Y, Z, 1.0f);
+  }
+}
+
+#endif
 // exclusive scan of a[0..n) by one 1024-thread block; returns the total (valid in every thread).  Per-thread
 // segments, a shuffle scan inside each wave and the 16 wave totals through LDS: two barriers (the Hillis-Steele
 // scan over 1024 LDS entries it replaces took twenty).  s_part: >= 16 ints.
@@ -1575,10 +2134,39 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst<false>), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
     attr_set = true;
   }
+  // Banded (several workgroups per level and frame) when a level does not fit the single-workgroup union-find -- 1280x960
+  // then builds in 1.25 ms instead of 1.75 ms with the flood fill; at 640x480 the four kernels of the banded path take as
+  // long as the one workgroup per (level, frame) (78 vs 79 us per 64 frames: measured, profiles/r03_hyst_banding.txt), so
+  // that size keeps the single kernel.  REVO_HYST_BANDED=1 / 0 forces either.
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("REVO_HYST_BANDED"); force = (e && *e) ? (*e != '0' ? 1 : 0) : -1; }
+  const bool fits_single = ec_bytes + 4096 <= REVO_HYST_LDS_MAX;
+  const bool banded = force >= 0 ? force == 1 : !fits_single;
+  const int only_flagged = banded && g.total_bands > 0 ? 1 : 0;
+  if (only_flagged) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst_band), hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS_WORDS * 4);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst_out), hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS_WORDS * 4);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst_seam), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipGetLastError();  // (a refused attribute must not surface as the error of the next launch check)
+      attr2 = true;
+    }
+    size_t seam_lds = 4, out_lds = 4;
+    for (int l = 0; l < g.n_levels; ++l) {
+      const LevelGeom& lv = g.lv[l];
+      const size_t nwb = (size_t)lv.band_rows * lv.wpr;
+      out_lds = std::max(out_lds, nwb * 4);
+      if (lv.nbands > 1) seam_lds = std::max(seam_lds, (size_t)lv.nbands * (size_t)(HB_LDS_WORDS / 2 / 32 + 64) * 4);
+    }
+    hipLaunchKernelGGL(k_hyst_band, dim3(g.total_bands * B), dim3(HB_THREADS), HB_LDS_WORDS * 4, s, g, p);
+    if (g.any_banded) hipLaunchKernelGGL(k_hyst_seam, dim3(g.n_levels * B), dim3(HS_THREADS), seam_lds, s, g, p);
+    hipLaunchKernelGGL(k_hyst_out, dim3(g.total_bands * B), dim3(HO_THREADS), out_lds, s, g, p);
+  }
   if (ec_bytes + 4096 <= REVO_HYST_LDS_MAX)  // candidate bitmap + union-find labels in LDS: all of it (one workgroup per CU anyway)
-    hipLaunchKernelGGL(k_hyst<true>, dim3(g.n_levels * B), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p);
+    hipLaunchKernelGGL(k_hyst<true>, dim3(only_flagged ? std::min(32, g.n_levels * B) : g.n_levels * B), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p, only_flagged, B);
   else  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
-    hipLaunchKernelGGL(k_hyst<false>, dim3(g.n_levels * B), dim3(HYST_THREADS), e_bytes, s, g, p);
+    hipLaunchKernelGGL(k_hyst<false>, dim3(only_flagged ? std::min(32, g.n_levels * B) : g.n_levels * B), dim3(HYST_THREADS), e_bytes, s, g, p, only_flagged, B);
 }
 
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
