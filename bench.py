@@ -182,7 +182,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pairs", type=int, default=32, help="frame-pairs per GPU per step")
-    ap.add_argument("--buffers", type=int, default=2, help="batches in rotation (2 = double-buffered: build k+1 overlaps tracker k)")
+    ap.add_argument("--buffers", type=int, default=3,
+                    help="batches in rotation: 3 = the build of step k+2 next to the tracker grids of steps k+1 and k (the library's "
+                         "resident gate keeps two tracker grids in flight); 2 = round 2's double buffering")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
@@ -288,7 +290,7 @@ def main():
         # a seeded synthetic camera sweep (TUM-like inter-frame motion: ~4 mm, 1 deg per frame)
         seq = synth.make_sequence(7, s, n_seq, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
         stream_frames = [(f[0], f[1], f[2]) for f in seq]
-        vo.REVO(s, cameraPyr=cam).run(stream_frames[:6])  # warm-up (pools, first-touch)
+        vo.REVO(s, cameraPyr=cam).run(stream_frames)  # warm-up: one full-length run (pools, first touch of every slot, code paths)
         runs = []
         for _ in range(max(1, a.single_stream_runs)):  # all runs reported, the MEDIAN is the figure
             drv = vo.REVO(s, cameraPyr=cam)
@@ -531,8 +533,10 @@ def main():
                         % (a.width, a.height, a.levels, a.pairs, 2 if world == 1 else 4),
             "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
             "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
-            "pipelining": "none" if a.no_overlap else ("double-buffered: build of step k+1 overlaps tracker of step k; consecutive tracker "
-                                                        "grids on %d stream(s), ordered by the library's resident gate" % len(s_tracks)),
+            "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
+                                                        "earlier ones; consecutive tracker grids on %d stream(s), ordered by the library's "
+                                                        "resident gate (at most two in flight)" % (nbuf, a.pairs, len(s_tracks))),
+            "batches_in_rotation": nbuf, "pairs_resident": nbuf * a.pairs,
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -94,6 +94,7 @@ struct revo_ctx {
   hipStream_t build_stream;  // pyramid builds of the single-frame API (overlap with tracking, like the IO thread)
   std::mutex mu;
   std::vector<FrameSet*> pool;  // free single-frame FrameSets
+  int framesets_created = 0;    // single-frame FrameSets that exist (free or in use)
   std::vector<Past> past_pool;  // recycled past-cloud buffers (no hipMalloc per frame)
   // single-pair tracker scratch
   // the kernel reads the descriptor from its argument segment and writes the result straight into
@@ -257,12 +258,15 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
   }
 }
 
-// Workgroups per frame-pair.  Every member of every cluster must be resident at once (they
-// exchange partial sums inside the launch), so the grid stays at <= 75 % of what the device
-// can hold for this kernel; the in-kernel wait is bounded as a second line of defence.
+// Workgroups per frame-pair.  Every member of every cluster must be resident at once (they exchange partial sums inside
+// the launch).  A batch grid takes HALF of what the device can hold for this kernel: the resident gate keeps the tracker
+// grids of two consecutive batches in flight (the second fills the CUs the first one's finished pairs free), and two
+// half-chip grids are resident together, whereas a 75 % grid (round 2) leaves the next one waiting with workgroups that
+// hold CUs and spin (measured, 32 pairs, three batches in rotation: cluster 6 -> 68.5 k, 4 -> 78.2 k, 3 -> 79.2 k frames/s;
+// a launch alone: 0.39 / 0.45 / 0.50 ms).  The in-kernel wait is bounded as a second line of defence.
 static int pick_cluster(const revo_ctx* c, int n_pairs) {
   const int resident = c->num_cus * c->blocks_per_cu;
-  int cl = (int)(0.75 * resident) / std::max(1, n_pairs);
+  int cl = (int)((n_pairs == 1 ? 0.75 : 0.5) * resident) / std::max(1, n_pairs);
   // a single pair: its members share one XCD (blockIdx % 8), i.e. 32 CUs -- 16 workgroups leave half of them
   // to the build kernels of the next frame
   if (n_pairs == 1) cl = std::min(cl, 16);
@@ -500,6 +504,25 @@ extern "C" void revo_ctx_destroy(revo_ctx* c) {
   pairs_jobs_release(c);  // the job slots hold batches, and batches hold the context
   ctx_unref(c);
 }
+// Single-frame FrameSets (20 MB of HBM + 2 MB of pinned staging each) are pooled, but the pool only grew on demand: the
+// first full-length run of a sequential driver paid a hipMalloc + hipHostMalloc per new frame in flight (bench r02:
+// first run 5x slower than the rest).  A driver that knows its queue depth reserves them up front.
+extern "C" int revo_ctx_reserve_framesets_(revo_ctx* c, int total) {
+  if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
+  HIPCHECK(hipSetDevice(c->device));
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      if (c->framesets_created >= total) return REVO_OK;
+      c->framesets_created += 1;
+    }
+    FrameSet* fs = nullptr;
+    const int rc = frameset_create(c, 1, true, &fs);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (rc) { c->framesets_created -= 1; return rc; }
+    c->pool.push_back(fs);
+  }
+}
 // used by revo_vo.hip
 extern "C" void revo_ctx_retain_(revo_ctx* c) { if (c) ctx_ref(c); }
 extern "C" void revo_ctx_release_(revo_ctx* c) { if (c) ctx_unref(c); }
@@ -547,6 +570,8 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   if (!fs) {
     int rc = frameset_create(c, 1, true, &fs);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->framesets_created += 1;
   }
   // The reference clones its inputs (imgpyramidrgbd.cpp:51,54): the host copy into the pinned
   // staging area below is that clone -- the caller may reuse its buffers when this returns.

@@ -1639,75 +1639,6 @@ __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) 
   if (tid == 0) pl.npts[f * REVO_L + l] = total;
 }
 
-#ifdef PT_OLD
-#define PT_TILES 8                 // tiles (half-waves) per block of k_pts_tiles
-#define PT_PITCH 36                // floats per staged depth row (16-byte aligned rows, banks spread)
-__global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
-  __shared__ float s_depth[PT_TILES][32 * PT_PITCH];
-  // 1-D grid, frame fastest (the tile groups of a frame share one XCD's L2)
-  const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
-  const int nB = gridDim.x / groups;
-  const int f = g.frame0 + blockIdx.x % nB;
-  const int tg = (blockIdx.x / nB) * PT_TILES + (threadIdx.x >> 5);
-  if (tg >= g.total_tiles) return;
-  int l = 0, t = tg;
-  for (int k = 0; k < g.n_levels; ++k) {
-    const int n = g.lv[k].wpr * g.lv[k].nchunk;
-    if (t < n) { l = k; break; }
-    t -= n;
-  }
-  const LevelGeom& lv = g.lv[l];
-  const int wpr = lv.wpr, h = lv.h, w = lv.w;
-  const int c = t / wpr, wc = t - c * wpr;
-  const int r = threadIdx.x & 31;
-  const int y0 = c * 32, x0 = wc * 32, y = y0 + r;
-  const bool has_vb = l < g.n_levels - 1;
-  const uint2* csw = pl.cs[l] + (size_t)f * h * wpr;
-  const float* depth = pl.depth[l] + (size_t)f * lv.npix;
-  const uint32_t E = y < h ? csw[(size_t)y * wpr + wc].y : 0u;
-  uint32_t v = (has_vb && y < h) ? tile_valid_word(g, pl, l, f, y, wc, E) : E;
-  // nothing to emit in this tile (half-wave uniform): no depth traffic at all
-  unsigned long long any = __ballot(v != 0u);
-  any = (threadIdx.x & 32) ? (any >> 32) : (any & 0xffffffffull);
-  if (!any) return;
-  // the tile's depths: 8 rows x 128 B per step, whole rows of the tile side by side in LDS
-  float* sd = s_depth[threadIdx.x >> 5];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int rr = 4 * k + (r >> 3), xs = 4 * (r & 7);
-    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y0 + rr < h && x0 + xs < w) d = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + rr) * w + x0 + xs);  // w is a multiple of 4
-    *reinterpret_cast<float4*>(sd + rr * PT_PITCH + xs) = d;
-  }
-  // (the half-wave reads what it wrote itself: program order within the wave is enough)
-  if (!has_vb) {  // the coarsest level has no validity bits: the depth test of imgpyramidrgbd.cpp:208 on the staged tile
-    uint32_t ok = 0;
-    for (uint32_t m = v; m; m &= m - 1) {
-      const int b = __ffs(m) - 1;
-      if (depth_ok(sd[r * PT_PITCH + b], g.depth_min, g.depth_max)) ok |= 1u << b;
-    }
-    v = ok;
-  }
-  const int cnt = __popc(v);
-  int incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    const int u = __shfl_up(incl, o, 32);
-    if (r >= o) incl += u;
-  }
-  const int base = pl.tile_base[(size_t)f * g.total_tiles + tg] + incl - cnt;
-  float4* out = pl.pts_trk[l] + (size_t)f * lv.npix + base;
-  int o = 0;
-  for (uint32_t m = v; m; m &= m - 1, ++o) {
-    const int b = __ffs(m) - 1;
-    const float Z = sd[r * PT_PITCH + b];
-    const float X = __fdiv_rn(Z * ((float)(x0 + b) - lv.cx), lv.fx);
-    const float Y = __fdiv_rn(Z * ((float)y - lv.cy), lv.fy);
-    out[o] = make_float4(X, Y, Z, 1.0f);
-  }
-}
-
-#else
 #define PT_TILES 8                 // tiles (half-waves) per block of k_pts_tiles
 #define PT_PITCH 36                // floats per staged depth row (16-byte aligned rows, banks spread)
 __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
@@ -1747,8 +1678,9 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int rr = 4 * k + (r >> 3), xs = 4 * (r & 7);
+      const bool row_has_points = __shfl((int)v, rr, 32) != 0;  // rows without a candidate point are never read: their lines stay in HBM
       d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (y0 + rr < h && x0 + xs < w) d[k] = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + rr) * w + x0 + xs);  // w is a multiple of 4
+      if (row_has_points && y0 + rr < h && x0 + xs < w) d[k] = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + rr) * w + x0 + xs);  // w is a multiple of 4
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(sd + (4 * k + (r >> 3)) * PT_PITCH + 4 * (r & 7)) = d[k];
@@ -1790,7 +1722,6 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
   }
 }
 
-#endif
 // exclusive scan of a[0..n) by one 1024-thread block; returns the total (valid in every thread).  Per-thread
 // segments, a shuffle scan inside each wave and the 16 wave totals through LDS: two barriers (the Hillis-Steele
 // scan over 1024 LDS entries it replaces took twenty).  s_part: >= 16 ints.

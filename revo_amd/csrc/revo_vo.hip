@@ -11,6 +11,7 @@
 extern "C" void revo_ctx_retain_(revo_ctx*);
 extern "C" void revo_ctx_release_(revo_ctx*);
 extern "C" void revo_tracker_reset_past_(revo_ctx*);
+extern "C" int revo_ctx_reserve_framesets_(revo_ctx*, int total);
 // split single-pair calls (revo_host.hip): launch now, read the result later
 extern "C" int revo_track_launch_(revo_ctx*, const revo_pyr* ref, const revo_pyr* curr, const float R[9], const float T[3], int slot,
                                   unsigned* seq_out);
@@ -95,6 +96,9 @@ extern "C" int revo_vo_set_max_queue(revo_vo* v, int max_queue) {
   if (!v) return REVO_ERR_INVALID_ARG;
   { std::lock_guard<std::mutex> lk(v->qmu); v->max_queue = max_queue; v->closed = false; }  // (re-)opens the stream
   v->qcv.notify_all();
+  // the frames a run holds at once: the queue, the one being submitted, the one being tracked, the previous one, the keyframe
+  // and one being recycled -- reserved now, not grown frame by frame during the first run
+  if (max_queue > 0) return revo_ctx_reserve_framesets_(v->ctx, max_queue + 5);
   return REVO_OK;
 }
 // the producer has no more frames: revo_vo_wait_frame returns 0 once the queue has drained
