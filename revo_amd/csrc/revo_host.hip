@@ -73,6 +73,8 @@ struct FrameSet {
   uint8_t* h_bgr = nullptr;
   float* h_depth = nullptr;
   hipEvent_t ev_ready = nullptr;  // recorded on the build stream after the last build kernel
+  hipEvent_t ev_aux = nullptr;    // (batches) the keyframe EDT on the batch's side stream: not owned by the set
+  bool has_aux = false;
   hipEvent_t ev_free = nullptr;   // recorded on the tracker stream when the set goes back to the pool
   bool has_ready = false, has_free = false;
 };
@@ -412,10 +414,10 @@ static void frameset_destroy(FrameSet* fs) {
 // with_points = false: stops after fillInEdges; the caller enqueues launch_tile_points itself (batches run it next to the EDT)
 static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
                           const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false,
-                          bool with_points = true) {
+                          bool with_points = true, int frame0 = 0, int nframes = -1) {
   PyrGeom g = c->geom;
-  g.frame0 = 0;
-  const int B = fs->B;
+  g.frame0 = frame0;
+  const int B = nframes < 0 ? fs->B : nframes;
   fs->p.depth[0] = (borrow_depth && d_depth_f32) ? const_cast<float*>(d_depth_f32) : fs->own_depth0;
   launch_gray_depth(g, fs->p, d_bgr, d_depth_f32, d_depth_u16, alpha, B, s);
   for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, B, s);
@@ -552,6 +554,7 @@ static int wait_ready(revo_ctx* c, const revo_pyr* p) {
   // single-frame pyramids: built on the build stream; batch views: built on the batch's / the caller's stream
   // (revo_batch_build records the event) -- either way the consumer stream is ordered behind the build
   if (p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
+  if (p->fs->has_aux) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_aux, 0));
   return REVO_OK;
 }
 
@@ -1113,12 +1116,15 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   const PyrGeom& g = b->ctx->geom;
   if (b->side) {
+    // The batch's stream does NOT wait for the EDT: what needs it -- the tracker of this batch, the accessors of its views,
+    // the next build into the same planes -- waits for ev_join itself, so the next batch's first build kernels (on the
+    // caller's stream) can start while this batch's EDT is still running.
     HIPCHECK(hipEventRecord(b->ev_fork, s));
     HIPCHECK(hipStreamWaitEvent(b->side, b->ev_fork, 0));
     launch_keyframe(g, b->fs->p, 0, 2, b->n_pairs, b->side);  // frame 2i = keyframe of pair i
     HIPCHECK(hipEventRecord(b->ev_join, b->side));
+    b->fs->ev_aux = b->ev_join; b->fs->has_aux = true;
     launch_tile_points(g, b->fs->p, b->fs->B, s);
-    HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
   } else {
     launch_tile_points(g, b->fs->p, b->fs->B, s);
     launch_keyframe(g, b->fs->p, 0, 2, b->n_pairs, s);
@@ -1134,6 +1140,8 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   // and with the round-2 kernels the step goes from 0.64 ms to 0.73 / 0.84 ms next to a tracker -- the build
   // kernels are throughput-limited, smaller launches only add tails.)
   b->last_results = nullptr;  // records of an earlier launch are the caller's business again
+  if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));  // the previous build's EDT still reads these planes
+  // (Measured and not kept: the two halves of the batch as two concurrent kernel chains -- 78.4 k -> 70.5 k frames/s.)
   enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
@@ -1172,6 +1180,7 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
+  if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));  // the keyframes' EDT (side stream of the build)
   b->last_results = d_results;
   return chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
     return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
@@ -1187,6 +1196,7 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
   b->last_results = nullptr;
+  if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
@@ -1208,6 +1218,7 @@ extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
   HIPCHECK(hipStreamSynchronize(s));
+  if (b->side) HIPCHECK(hipStreamSynchronize(b->side));  // (the keyframes' EDT of the last build)
   // A record with bit 3 carries no pose (its workgroups could not exchange partial sums: device shared with
   // another process): that is an error of the call, not something to find by decoding flags.
   if (b->last_results) {
@@ -1405,6 +1416,7 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
+  if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
