@@ -1640,9 +1640,15 @@ __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) 
 }
 
 #define PT_TILES 8                 // tiles (half-waves) per block of k_pts_tiles
-#define PT_PITCH 36                // floats per staged depth row (16-byte aligned rows, banks spread)
+// Half a wavefront per 32 x 32 tile.  Lane r reads row r's word of (edge bitmap AND validity bits), the rows' counts are
+// scanned across the half-wave, every lane records WHERE its row's points are (row << 5 | column, a few instructions per
+// point: a row of a horizontal edge holds up to 32 points, a row crossed by a vertical edge one), and then the
+// back-projection is dealt out evenly: lane k takes list positions k, k + 32, ... of the tile, gathers that pixel's depth
+// (consecutive positions are neighbours in a row: a gather touches a handful of lines), divides twice and stores --
+// consecutive lanes write consecutive 16-byte entries.  No depth staging, ~32 VGPRs, 2 KB of LDS per tile: the kernel
+// keeps its occupancy next to the trackers and the EDT it runs beside (the round-3 version that staged 4 KB depth tiles
+// through LDS took 33 us alone but 120 us in the pipelined step).
 __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
-  __shared__ float s_depth[PT_TILES][32 * PT_PITCH];
   __shared__ unsigned short s_src[PT_TILES][1024];  // list position inside the tile -> (row << 5 | column)
   // 1-D grid, frame fastest (the tile groups of a frame share one XCD's L2)
   const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
@@ -1667,33 +1673,11 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
   const int tile_first = pl.tile_base[(size_t)f * g.total_tiles + tg];  // (requested early: needed last)
   const uint32_t E = y < h ? csw[(size_t)y * wpr + wc].y : 0u;
   uint32_t v = (has_vb && y < h) ? tile_valid_word(g, pl, l, f, y, wc, E) : E;
-  // nothing to emit in this tile (half-wave uniform): no depth traffic at all
-  unsigned long long any = __ballot(v != 0u);
-  any = (threadIdx.x & 32) ? (any >> 32) : (any & 0xffffffffull);
-  if (!any) return;
-  // the tile's depths: 8 rows x 128 B per step, whole rows of the tile side by side in LDS
-  float* sd = s_depth[threadIdx.x >> 5];
-  {
-    float4 d[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int rr = 4 * k + (r >> 3), xs = 4 * (r & 7);
-      const bool row_has_points = __shfl((int)v, rr, 32) != 0;  // rows without a candidate point are never read: their lines stay in HBM
-      d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_has_points && y0 + rr < h && x0 + xs < w) d[k] = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + rr) * w + x0 + xs);  // w is a multiple of 4
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(sd + (4 * k + (r >> 3)) * PT_PITCH + 4 * (r & 7)) = d[k];
-  }
-  // (the half-wave reads what it wrote itself: program order within the wave is enough)
-  if (!has_vb) {  // the coarsest level has no validity bits: the depth test of imgpyramidrgbd.cpp:208 on the staged tile
-    uint32_t ok = 0;
+  if (!has_vb)   // the coarsest level has no validity bits: the depth test of imgpyramidrgbd.cpp:208, like k_tile_count
     for (uint32_t m = v; m; m &= m - 1) {
       const int b = __ffs(m) - 1;
-      if (depth_ok(sd[r * PT_PITCH + b], g.depth_min, g.depth_max)) ok |= 1u << b;
+      if (!depth_ok(depth[(size_t)y * w + x0 + b], g.depth_min, g.depth_max)) v &= ~(1u << b);
     }
-    v = ok;
-  }
   const int cnt = __popc(v);
   int incl = cnt;
 #pragma unroll
@@ -1702,23 +1686,28 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
     if (r >= o) incl += u;
   }
   const int total = __shfl(incl, 31, 32);
-  // Row r's points sit at positions incl - cnt .. incl - 1 of the tile.  A row of a horizontal edge holds up to 32 of them,
-  // a row crossed by a vertical edge one: each lane only records WHERE its points are (a few instructions per point) ...
+  if (total == 0) return;  // (half-wave uniform)
   unsigned short* src = s_src[threadIdx.x >> 5];
   {
     int o = incl - cnt;
     for (uint32_t m = v; m; m &= m - 1, ++o) src[o] = (unsigned short)((r << 5) | (__ffs(m) - 1));
   }
-  // ... and the back-projection (two correctly rounded divisions per point) and the stores are dealt out evenly: lane k takes
-  // positions k, k + 32, ...: consecutive lanes write consecutive 16-byte entries
+  // (the half-wave reads what it wrote itself: program order within the wave is enough)
   float4* out = pl.pts_trk[l] + (size_t)f * lv.npix + tile_first;
-  for (int k = r; k < total; k += 32) {
-    const int rb = src[k];
-    const int rr = rb >> 5, b = rb & 31;
-    const float Z = sd[rr * PT_PITCH + b];
-    const float X = __fdiv_rn(Z * ((float)(x0 + b) - lv.cx), lv.fx);
-    const float Y = __fdiv_rn(Z * ((float)(y0 + rr) - lv.cy), lv.fy);
-    out[k] = make_float4(X, Y, Z, 1.0f);
+  for (int k0 = r; k0 < total; k0 += 4 * 32) {  // four positions per lane and trip: their gathers are in flight together
+    int rb[4];
+    float Z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = k0 + 32 * q < total ? (int)src[k0 + 32 * q] : -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Z[q] = rb[q] >= 0 ? depth[(size_t)(y0 + (rb[q] >> 5)) * w + x0 + (rb[q] & 31)] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (rb[q] < 0) continue;
+      const float X = __fdiv_rn(Z[q] * ((float)(x0 + (rb[q] & 31)) - lv.cx), lv.fx);
+      const float Y = __fdiv_rn(Z[q] * ((float)(y0 + (rb[q] >> 5)) - lv.cy), lv.fy);
+      out[k0 + 32 * q] = make_float4(X, Y, Z[q], 1.0f);
+    }
   }
 }
 
