@@ -37,6 +37,7 @@ struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
   int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
+  int nms_px;          // pixels per thread of the Canny NMS kernel the block counts below were made for (8 or 4)
   int total_bands, any_banded;  // hysteresis bands of all levels; 1 if some level has more than one
   int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
   float depth_min, depth_max;

@@ -385,6 +385,130 @@ __global__ void __launch_bounds__(256) NMS_OCC k_canny_nms(PyrGeom g, FramePlane
   static_assert(NMS_R == 6, "six steps above");
 }
 
+// The same kernel with FOUR pixels per thread (columns -1 .. 4 in flight instead of -1 .. 8): ~60 registers instead of
+// 104.  It runs ~14 % more instructions (the halo columns are shared by fewer outputs), but the build shares every CU
+// with two resident tracker workgroups (2 x 168 VGPRs per SIMD lane slot): 176 registers are left, i.e. ONE wave per SIMD
+// of the 8-pixel kernel (42 us alone, 82-89 us in the pipelined step) against two or three of this one.
+struct HRow4 { s2v d[3], s[3]; };  // column pairs (-1,0) (1,2) (3,4)
+__device__ __forceinline__ HRow4 hrow4(uint32_t prev, uint32_t m0, uint32_t next) {  // prev = g[-4..-1], m0 = g[0..3], next = g[4..7]
+  const s2v E0 = PAIR(0u, prev, 0x0c030c02u), E1 = PAIR(0u, m0, 0x0c010c00u), E2 = PAIR(0u, m0, 0x0c030c02u), E3 = PAIR(0u, next, 0x0c010c00u);
+  const s2v O0 = PAIR(m0, prev, 0x0c040c03u), O1 = PAIR(0u, m0, 0x0c020c01u), O2 = PAIR(next, m0, 0x0c040c03u);
+  HRow4 r;
+  r.d[0] = E1 - E0; r.d[1] = E2 - E1; r.d[2] = E3 - E2;
+  r.s[0] = (E0 + E1) + (O0 + O0); r.s[1] = (E1 + E2) + (O1 + O1); r.s[2] = (E2 + E3) + (O2 + O2);
+  return r;
+}
+struct MRow4 { int v0, v1, v2, v3, v4, v5; };   // |grad|^2 of columns -1..4
+struct DRow4 { uint32_t v0, v1, v2, v3; };      // (dx | dy << 16) of columns 0..3
+__device__ __forceinline__ void mag_row4(const HRow4& a, const HRow4& b, const HRow4& c, uint32_t cm_left, uint32_t cm_right, bool valid,
+                                         MRow4& m, DRow4& dxy) {
+  uint32_t lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const s2v dx = (a.d[k] + c.d[k]) + (b.d[k] + b.d[k]);
+    const s2v dy = c.s[k] - a.s[k];
+    lo[k] = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x05040100u);
+    hi[k] = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x07060302u);
+  }
+  const uint32_t rv = valid ? ~0u : 0u;
+#define MAG2(x) __builtin_amdgcn_sdot2(as_s2(x), as_s2(x), 0, false)
+  m.v0 = MAG2(lo[0]) & (int)(cm_left & rv);
+  m.v1 = MAG2(hi[0]) & (int)rv;
+  m.v2 = MAG2(lo[1]) & (int)rv;
+  m.v3 = MAG2(hi[1]) & (int)rv;
+  m.v4 = MAG2(lo[2]) & (int)rv;
+  m.v5 = MAG2(hi[2]) & (int)(cm_right & rv);
+#undef MAG2
+  dxy.v0 = hi[0]; dxy.v1 = lo[1]; dxy.v2 = hi[1]; dxy.v3 = lo[2];
+}
+__device__ __forceinline__ void nms_row4(const MRow4& A, const MRow4& B, const MRow4& C, const DRow4& d, int low, int high,
+                                         uint32_t* cand, uint32_t* strong) {
+  uint32_t cb = 0, sb = 0;
+  nms_px(0, A.v0, A.v1, A.v2, B.v0, B.v1, B.v2, C.v0, C.v1, C.v2, d.v0, low, high, cb, sb);
+  nms_px(1, A.v1, A.v2, A.v3, B.v1, B.v2, B.v3, C.v1, C.v2, C.v3, d.v1, low, high, cb, sb);
+  nms_px(2, A.v2, A.v3, A.v4, B.v2, B.v3, B.v4, C.v2, C.v3, C.v4, d.v2, low, high, cb, sb);
+  nms_px(3, A.v3, A.v4, A.v5, B.v3, B.v4, B.v5, C.v3, C.v4, C.v5, d.v3, low, high, cb, sb);
+  *cand = cb;
+  *strong = sb;
+}
+__global__ void __launch_bounds__(256) k_canny_nms4(PyrGeom g, FramePlanes pl) {
+  const int f = g.frame0 + blockIdx.z;
+  if (blockIdx.x == 0 && threadIdx.x < REVO_L) {  // per-frame words the banded hysteresis accumulates into / raises
+    pl.need_full[f * REVO_L + threadIdx.x] = 0;
+    pl.hist_nz[f * REVO_L + threadIdx.x] = 0;
+  }
+  const int l = level_of(g, blockIdx.x, &LevelGeom::nms_block_base);
+  const LevelGeom& lv = g.lv[l];
+  const int w = lv.w, h = lv.h;
+  const int rt = 8 * lv.wpr;  // threads per row: eight threads make one 32-pixel bitmap word
+  const int t = (blockIdx.x - lv.nms_block_base) * 256 + threadIdx.x;
+  const int yb = t / rt, xg = t - yb * rt;
+  const int y0 = yb * NMS_R;
+  if (y0 >= h) return;  // whole groups of eight leave together (rt is a multiple of 8)
+  const int x = xg * 4;
+  const bool active = x < w;
+  const uint8_t* gray = pl.gray[l] + (size_t)f * lv.npix;
+  const bool has_prev = x > 0, has_next = x + 4 < w;
+  const int xo = active ? x : 0;
+  const int o_prev = (active && has_prev) ? xo - 4 : xo, o_next = (active && has_next) ? xo + 4 : xo;
+  const uint32_t cm_left = (active && has_prev) ? ~0u : 0u, cm_right = (active && has_next) ? ~0u : 0u;
+  struct Raw { uint32_t prev, m0, next; };
+  auto load_raw = [&](int r) -> Raw {
+    const int rr = clampi(r, 0, h - 1);  // BORDER_REPLICATE
+    const uint8_t* row = gray + (size_t)rr * w;
+    Raw q;
+    q.m0 = *reinterpret_cast<const uint32_t*>(row + xo);
+    q.prev = *reinterpret_cast<const uint32_t*>(row + o_prev);
+    q.next = *reinterpret_cast<const uint32_t*>(row + o_next);
+    return q;
+  };
+  auto make_hrow = [&](Raw q) -> HRow4 {
+    if (!has_prev) q.prev = (q.m0 & 0xffu) * 0x01010101u;
+    if (!has_next) q.next = (q.m0 >> 24) * 0x01010101u;
+    return hrow4(q.prev, q.m0, q.next);
+  };
+  HRow4 H0, H1, H2;
+  MRow4 M0, M1, M2;
+  DRow4 D0, D1, D2;
+  {
+    const Raw r0 = load_raw(y0 - 2), r1 = load_raw(y0 - 1), r2 = load_raw(y0), r3 = load_raw(y0 + 1);
+    H0 = make_hrow(r0); H1 = make_hrow(r1); H2 = make_hrow(r2);
+    mag_row4(H0, H1, H2, cm_left, cm_right, active && y0 - 1 >= 0, M0, D0);   // magnitude row y0 - 1
+    H0 = make_hrow(r3);
+  }
+  Raw ahead = load_raw(y0 + 2);
+  mag_row4(H1, H2, H0, cm_left, cm_right, active, M1, D1);                    // magnitude row y0
+  uint2* out = pl.cs[l] + ((size_t)f * h + y0) * lv.wpr + (xg >> 3);
+  const int sh = 4 * (threadIdx.x & 7);
+  auto emit = [&](int i, uint32_t cb, uint32_t sb) {
+    // eight threads' nibbles -> one word (DPP: two quad permutes, then the other quad through row_half_mirror)
+    uint32_t cw = cb << sh, sw = sb << sh;
+    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0xB1, 0xf, 0xf, true);
+    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0x4E, 0xf, 0xf, true);
+    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane i <-> 7 - i
+    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0x141, 0xf, 0xf, true);
+    if ((threadIdx.x & 7) == 0 && y0 + i < h) out[(size_t)i * lv.wpr] = make_uint2(cw, sw);
+  };
+#define NMS_STEP4(i, Ha, Hb, Hc, Ma, Mb, Mc, Db, Dc)                                  \
+  {                                                                                   \
+    Hc = make_hrow(ahead);                                                            \
+    if ((i) < NMS_R - 1) ahead = load_raw(y0 + (i) + 3);                              \
+    mag_row4(Ha, Hb, Hc, cm_left, cm_right, active && y0 + (i) + 1 < h, Mc, Dc);      \
+    uint32_t cb, sb;                                                                  \
+    nms_row4(Ma, Mb, Mc, Db, g.canny_low, g.canny_high, &cb, &sb);                    \
+    emit((i), cb, sb);                                                                \
+  }
+  NMS_STEP4(0, H2, H0, H1, M0, M1, M2, D1, D2)
+  NMS_STEP4(1, H0, H1, H2, M1, M2, M0, D2, D0)
+  NMS_STEP4(2, H1, H2, H0, M2, M0, M1, D0, D1)
+  NMS_STEP4(3, H2, H0, H1, M0, M1, M2, D1, D2)
+  NMS_STEP4(4, H0, H1, H2, M1, M2, M0, D2, D0)
+  NMS_STEP4(5, H1, H2, H0, M2, M0, M1, D0, D1)
+#undef NMS_STEP4
+}
+
 // ---------------------------------------------------------------------------
 // a5 (second half): hysteresis.  cv::Canny keeps a candidate iff it is 8-connected, through
 // candidates, to a strong one.  One workgroup per (frame, level) holds the level's candidate bitmap C
@@ -2035,8 +2159,10 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
                      p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max);
 }
 
+// nms_px = pixels per thread the geometry's block counts were made for (revo_host.hip: build_geom): 8 or 4
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_canny_nms, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
+  if (g.nms_px == 4) hipLaunchKernelGGL(k_canny_nms4, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
+  else hipLaunchKernelGGL(k_canny_nms, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
 }
 
 // hysteresis + edge planes + tile histograms: one workgroup per (level, frame)
