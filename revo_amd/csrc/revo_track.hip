@@ -718,7 +718,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
     const bool redundant = cluster == 1 || N <= prm.redundant_n;
     const int stride = redundant ? TRACK_THREADS : cluster * TRACK_THREADS;
     const int first = redundant ? tid : member * TRACK_THREADS + tid;
-    ++epoch;
+    // the exchange counter only moves on passes that exchange: the two parity slots of the mailbox are safe only if every
+    // epoch is both published and gathered by every member (a redundant pass in between would let a fast member publish
+    // epoch e + 2 into the slot a slow member still polls for e); all members compute `redundant` alike, so they stay in step
+    if (!redundant) ++epoch;
 #ifdef REVO_TRACK_PROFILE
     const long long tp0 = clock64();
 #endif
