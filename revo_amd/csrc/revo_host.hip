@@ -326,8 +326,9 @@ static int chained_track_launch(int device, hipStream_t s, F&& launch) {
     if (ch.serial) HIPCHECK(hipStreamWaitEvent(s, ch.ev[prev], 0));                     // n-1 complete (round-2 behaviour)
     else launch_track_gate(ch.d_resident, ch.started_total, s);                         // n-1 fully resident
   }
-  ch.started_total += (unsigned)launch(ch.d_resident);
-  HIPCHECK(hipGetLastError());
+  const int n_wg = launch(ch.d_resident);
+  HIPCHECK(hipGetLastError());              // (a refused launch adds nothing to the census: the next gate must not wait for it)
+  ch.started_total += (unsigned)n_wg;
   HIPCHECK(hipEventRecord(ch.ev[cur], s));
   ch.has[cur] = true;
   ch.st[cur] = s;

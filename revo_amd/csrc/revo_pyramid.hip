@@ -3,13 +3,15 @@
 // promotion (makeKeyframe, imgpyramidrgbd.cpp:231-276).
 //
 // Integer/byte streaming and small stencils: coalesced dword/dwordx4 row accesses, the 3x3 stencil of
-// Canny entirely in registers (bitmaps out), hysteresis as a union-find over weak runs in the LDS of one
-// workgroup per (level, frame), 32 x 32 bit tiles transposed across lanes wherever a column-wise pass needs a
-// row-wise bitmap, LDS staging where a block's output is a contiguous range (ordered compaction).  One launch
-// covers every level of every frame in the batch; grids are 1-D and ordered so that the 8 XCDs (ids go
-// round-robin over them) either SHARE a frame's cache lines (frame-fastest: strips of one frame on one L2) or
-// SPREAD the expensive workgroups (level-major hysteresis).  No MFMA: there is no contraction anywhere on this
-// path.  What binds each kernel is tabulated in DESIGN.md 3.
+// Canny entirely in registers (bitmaps out; four pixels per thread so that the kernel keeps two waves per SIMD next to
+// the resident trackers), hysteresis as a union-find over weak runs in the LDS of one workgroup per (level, frame) --
+// or, for levels that do not fit, per band of rows with an exact seam pass --, the 3-D edge list written TILE-ORDERED
+// for the tracker (32 x 32-pixel tiles: a wavefront's points share a handful of DT rows) with the reference's
+// column-major order produced on demand, 32 x 32 bit tiles transposed across lanes wherever a column-wise pass needs a
+// row-wise bitmap.  One launch covers every level of every frame in the batch; grids are 1-D and ordered so that the
+// 8 XCDs (ids go round-robin over them) either SHARE a frame's cache lines (frame-fastest: strips / tiles of one frame
+// on one L2) or SPREAD the expensive workgroups (level-major hysteresis).  No MFMA: there is no contraction anywhere
+// on this path.  What binds each kernel is tabulated in DESIGN.md 3.
 //
 // Exactness: every integer stage is bit-exact by construction; float stages
 // keep the reference's operation order and are compiled with -ffp-contract=off.

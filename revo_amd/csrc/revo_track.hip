@@ -37,6 +37,15 @@
 // |diagonal|, left-looking, pseudo-inverse of D -- row-parallel across lanes, every element seeing the
 // serial algorithm's operations in the serial order.
 //
+// The points arrive TILE-ORDERED (revo_pyramid.hip: k_pts_tiles), not in the reference's column-major list order: the 64
+// points of a wavefront then project into a small neighbourhood of the keyframe's DT plane, and a gather instruction costs
+// the vector L1 one tag lookup per distinct cache line among its lanes -- with the column-major list that lookup rate, not
+// latency or HBM, bounded the evaluation (44 lines per gather; 27 now).  The order of a sum is not part of the interface.
+//
+// Launches of one device are ordered by a resident gate (revo_host.hip): every workgroup counts itself into a census
+// word when it starts, and the next grid may start once this one is completely resident -- two grids in flight, the
+// older one always whole on the chip.
+//
 // The gradient/DT float4 table of the reference (imgpyramidrgbd.cpp:255-276) is NOT read here: the
 // kernel samples the 4x smaller DT plane and forms the corner gradients 0.5*(dt[i-1]-dt[i+1]),
 // 0.5*(dt[i-w]-dt[i+w]) on the fly -- the same float operations, hence the same values.
