@@ -181,6 +181,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   g->canny_low = (int)std::floor(lo); g->canny_high = (int)std::floor(hi);
   g->use_edge_hist = s.use_edge_hist; g->n_percentage = s.n_percentage;
   int tile = 0, pix = 0, row = 0, col = 0, cc = 0, tiles32 = 0, bands = 0;
+  bool bands_fit = true;
   for (int l = 0; l < L; ++l) {
     LevelGeom& v = g->lv[l];
     const float scale = 1.0f / (float)std::pow(2, l);  // camerapyr.h:142
@@ -215,15 +216,18 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
       int rows = (env_int("REVO_HYST_BAND_WORDS", 2400, 64, 1 << 20) / v.wpr) / unit * unit;
       if (rows < unit) rows = unit;
       if (rows >= v.h) rows = v.h;
+      if ((v.h + rows - 1) / rows > 32) rows = ((v.h + 31) / 32 + unit - 1) / unit * unit;  // k_hyst_seam holds at most 32 bands' flags
       v.band_rows = rows;
       v.nbands = (v.h + rows - 1) / rows;
-      if (v.nbands > 32) { v.band_rows = v.h; v.nbands = 1; }  // (k_hyst_seam holds at most 32 bands' flags)
       v.band_base = bands; bands += v.nbands;
       if (v.nbands > 1) g->any_banded = 1;
+      // a band's bitmaps (weak words, 16-bit id bases, edge rows + halo) must leave room for tables in the 64 KB of a band workgroup
+      const size_t nwb = (size_t)rows * v.wpr;
+      if (nwb + (nwb + 2) / 2 + (size_t)(rows + 2) * v.wpr + 2 + 256 > 16384) bands_fit = false;
     }
   }
   g->total_tiles = tiles32;
-  g->total_bands = bands;
+  g->total_bands = bands_fit ? bands : 0;  // 0: no banded hysteresis for this geometry (k_hyst alone, as in round 2)
   for (int l = 1; l < L; ++l)  // fillInEdges' gate (imgpyramidrgbd.cpp:188-195 + the patch sizes that exist)
     g->lv[l].has_orig = (s.use_edge_hist && g->lv[l].patch > 0 && g->lv[l - 1].patch > 0) ? 1 : 0;
   g->total_nms_blocks = tile; g->total_pix = pix; g->total_edt_blocks = row; g->total_strips = col; g->total_cc = cc;
@@ -1326,7 +1330,15 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   }
   // H2D straight from the caller's rows (no host-side staging copy): one copy per plane (strided only when the
   // rows are padded), colour planes and depth planes on two streams so that two DMA engines work
-  hipStream_t cs = c->copy_stream, cs2 = c->copy_stream2;
+  // HIP multiplexes its streams over a few hardware queues, and a copy stream that shares a queue with a compute stream
+  // waits behind that stream's kernels: that, not the link, is why the f32 path reaches 20-24 GB/s where the u16 path
+  // reaches 40 (profiles/r03_host_buffer_streams.txt: GPU_MAX_HW_QUEUES=8 lifts f32 to 45 GB/s -- and costs the pipelined
+  // device-buffer batches a third of their throughput, so the library does not ask for it; swapping the planes' streams
+  // helped in one order of events and not in another: the mapping depends on the process's stream history).
+  // REVO_H2D_STREAMS: 1 = one copy stream for both planes, 2 = planes swapped (experiments).
+  static const int h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
+  hipStream_t cs = c->copy_stream, cs2 = h2d_mode == 1 ? c->copy_stream : c->copy_stream2;  // cs: colour, cs2: depth
+  if (h2d_mode == 2) std::swap(cs, cs2);
   // Any failure below must not leave the slot busy for ever (three of those and the context only ever answers
   // REVO_ERR_CAPACITY), nor return while the DMA engines may still be reading the caller's buffers.
   struct SlotGuard {
@@ -1341,7 +1353,7 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   } slot_guard{c, j, cs, cs2};
   bool any_init = false;
   auto upload = [&](void* dst, const void* src, size_t src_stride, size_t row_bytes, hipStream_t st) -> hipError_t {
-    if (src_stride == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * h, hipMemcpyHostToDevice, st);
+    if (src_stride == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * h, hipMemcpyHostToDevice, st);  // (pieces were measured: slower)
     return hipMemcpy2DAsync(dst, row_bytes, src, src_stride, row_bytes, h, hipMemcpyHostToDevice, st);
   };
   for (int i = 0; i < n; ++i) {

@@ -304,3 +304,45 @@ def test_shared_reciprocal_division_is_bit_identical_to_ieee(tmp_path):
                            os.path.join(root, "tests", "cpp", "div_exact.hip")], timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "TOTAL_MISMATCHES 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_tracker_grids_on_two_streams_overlap_under_the_resident_gate(api, ro):
+    """Round 3: tracker grids of one device are no longer serialised completely -- grid n+1 (another stream) may start once
+    every workgroup of grid n has started (census counter + gate kernel, revo_host.hip).  Three batches on two tracker
+    streams, several rounds back to back with nothing waiting in between: every record must equal the record the same
+    batch produces alone on one stream, bit for bit, and no record may carry flag 8 (a cluster that never completed)."""
+    import torch
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    n = 8
+    dev = torch.device("cuda", 0)
+    bts, inputs, ref = [], [], []
+    for b in range(3):
+        pairs = [synth.make_pair(500 + 10 * b + i, s) for i in range(n)]
+        bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).to(dev)
+        dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).to(dev)
+        bt = api.BatchTracker(cam, n)
+        res = torch.zeros(n * 96, dtype=torch.uint8, device=dev)
+        bt.track(bgr.data_ptr(), dep.data_ptr(), res.data_ptr())
+        bt.sync()
+        bts.append(bt); inputs.append((bgr, dep)); ref.append(res.cpu().numpy().tobytes())
+        assert all(r["flags"] & (2 | 4 | 8) == 0 for r in api.results_from_buffer(ref[-1], n))
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    s_build = torch.cuda.Stream(device=dev)
+    rounds = 6
+    outs = [torch.zeros(n * 96, dtype=torch.uint8, device=dev) for _ in range(3 * rounds)]
+    built = [torch.cuda.Event() for _ in range(3)]
+    tracked = [torch.cuda.Event() for _ in range(3)]
+    for t in range(3 * rounds):
+        b = t % 3
+        st = streams[t % 2]
+        s_build.wait_event(tracked[b])
+        bts[b].build(inputs[b][0].data_ptr(), inputs[b][1].data_ptr(), stream=s_build.cuda_stream)
+        built[b].record(s_build)
+        st.wait_event(built[b])
+        bts[b].track_only(outs[t].data_ptr(), stream=st.cuda_stream)
+        tracked[b].record(st)
+    torch.cuda.synchronize()
+    for t in range(3 * rounds):
+        assert outs[t].cpu().numpy().tobytes() == ref[t % 3], "step %d differs from the batch alone" % t
