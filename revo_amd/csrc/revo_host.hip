@@ -1083,7 +1083,11 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
   HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
-  if (!env_int("REVO_BUILD_NO_FORK", 0, 0, 1)) {
+  // REVO_BUILD_FORK=1: the keyframes' EDT on a side stream next to the edge-list kernels.  Off by default: when the two
+  // really run concurrently (their streams on different hardware queues) the pipelined step collapses (GPU_MAX_HW_QUEUES=8:
+  // 78.5 k -> 47.4 k frames/s), and with HIP's default four queues, where they mostly share a queue, it gains nothing
+  // (77.1 k with the fork, 78.7 k without).
+  if (env_int("REVO_BUILD_FORK", 0, 0, 1)) {
     HIPCHECK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
