@@ -369,6 +369,7 @@ def main():
             s_tr.wait_event(ev_built[k])
             if timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
                 e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                bts[k].prepare(stream=s_tr.cuda_stream)  # the keyframes' EDT the build left to this stream: not k_track
                 e_a.record(s_tr)
                 bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
                 e_b.record(s_tr)
@@ -467,6 +468,7 @@ def main():
     for _ in range(reps):
         e0.record()
         bt.build(d_bgr.data_ptr(), d_dep.data_ptr(), stream=stream, borrow_depth=True)
+        bt.prepare(stream=stream)  # the keyframes' EDT belongs to the build stage wherever it is run
         e1.record()
         bt.track_only(d_res.data_ptr(), stream=stream)
         e2.record()

@@ -290,6 +290,11 @@ int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const uint16_t* d_
                          double depth_scale_factor, void* stream);
 int revo_batch_track_only(revo_batch* b, const float* h_init_RT,
                           revo_pair_result* d_results, void* stream);
+/* Runs, on `stream`, whatever part of the last build was left to the batch's first consumer (today: the keyframes'
+ * distance transforms, keyframe.cpp:43-58 -- the build leaves them to the tracker's stream so the build stream is free
+ * for the next batch).  revo_batch_track_only does this itself; call it first only to keep that work outside a timed
+ * tracker launch.  No-op when nothing is pending. */
+int revo_batch_prepare(revo_batch* b, void* stream);
 int revo_batch_sync(revo_batch* b, void* stream);
 /* Pyramid view of frame f of the batch (owned by the batch). */
 int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out);

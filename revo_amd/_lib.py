@@ -94,6 +94,7 @@ def lib():
     L.revo_batch_build_borrow.argtypes = [vp, vp, vp, vp]
     L.revo_batch_build_u16.argtypes = [vp, vp, vp, C.c_double, vp]
     L.revo_batch_track_only.argtypes = [vp, f32p, vp, vp]
+    L.revo_batch_prepare.argtypes = [vp, vp]
     L.revo_batch_sync.argtypes = [vp, vp]
     L.revo_track_pairs_submit.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vpp]
     L.revo_track_pairs_wait.argtypes = [vp, vp]

@@ -349,6 +349,11 @@ class BatchTracker:
         """build() for raw uint16 depth (device pointer); the metres conversion is fused into the build."""
         check(_lib.lib().revo_batch_build_u16(self._h, d_bgr, d_depth_raw, float(depth_scale_factor), stream))
 
+    def prepare(self, stream=None):
+        """Runs on `stream` the part of the last build that was left to its first consumer (the keyframes' distance
+        transforms); track_only() does this itself -- call it first only to keep that work out of a timed launch."""
+        check(_lib.lib().revo_batch_prepare(self._h, stream))
+
     def track_only(self, d_results, init_RT=None, stream=None):
         keep, ptr = self._init(init_RT)
         check(_lib.lib().revo_batch_track_only(self._h, ptr, d_results, stream))

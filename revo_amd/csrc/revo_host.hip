@@ -75,6 +75,11 @@ struct FrameSet {
   hipEvent_t ev_ready = nullptr;  // recorded on the build stream after the last build kernel
   hipEvent_t ev_aux = nullptr;    // (batches) the keyframe EDT on the batch's side stream: not owned by the set
   bool has_aux = false;
+  // (batches) the keyframes' EDT has been DEFERRED to whoever needs it first -- normally the tracker launch of the batch, on
+  // the tracker's stream: the build stream is the critical one of the pipelined step and the tracker streams have slack
+  std::mutex edt_mu;
+  bool edt_pending = false;
+  int edt_count = 0;              // keyframes: frames 0, 2, 4, ...
   hipEvent_t ev_free = nullptr;   // recorded on the tracker stream when the set goes back to the pool
   bool has_ready = false, has_free = false;
 };
@@ -556,11 +561,22 @@ extern "C" int revo_ctx_camera(const revo_ctx* c, int lvl, float out6[6]) {
 
 // ----------------------------------------------------------------- pyramids --
 // Order the consumer stream after the (asynchronous) build of a single-frame pyramid.
+// Runs a deferred keyframe EDT of the set on stream s (which is first ordered behind the build).
+static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(fs->edt_mu);
+  if (!fs->edt_pending) return REVO_OK;
+  if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, fs->ev_ready, 0));
+  launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
+  HIPCHECK(hipGetLastError());
+  fs->edt_pending = false;
+  return REVO_OK;
+}
 static int wait_ready(revo_ctx* c, const revo_pyr* p) {
   // single-frame pyramids: built on the build stream; batch views: built on the batch's / the caller's stream
   // (revo_batch_build records the event) -- either way the consumer stream is ordered behind the build
   if (p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
   if (p->fs->has_aux) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_aux, 0));
+  if (p->fs->edt_pending) return run_pending_edt(c, p->fs, c->stream);  // an accessor / single-pair call on a batch view came first
   return REVO_OK;
 }
 
@@ -1135,6 +1151,12 @@ static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
     HIPCHECK(hipEventRecord(b->ev_join, b->side));
     b->fs->ev_aux = b->ev_join; b->fs->has_aux = true;
     launch_tile_points(g, b->fs->p, b->fs->B, s);
+  } else if (env_int("REVO_EDT_DEFER", 1, 0, 1)) {
+    // the EDT of the keyframes is left to its first consumer (run_pending_edt): the batch's tracker launch runs it on ITS
+    // stream, in front of the grid -- 97 us less on the build stream, which is the critical one of the pipelined step
+    launch_tile_points(g, b->fs->p, b->fs->B, s);
+    std::lock_guard<std::mutex> lk(b->fs->edt_mu);
+    b->fs->edt_pending = true; b->fs->edt_count = b->n_pairs;
   } else {
     launch_tile_points(g, b->fs->p, b->fs->B, s);
     launch_keyframe(g, b->fs->p, 0, 2, b->n_pairs, s);
@@ -1182,6 +1204,14 @@ static int batch_upload_init(revo_batch* b, const float* h_init_RT, hipStream_t 
   return REVO_OK;
 }
 
+extern "C" int revo_batch_prepare(revo_batch* b, void* stream) {
+  if (!b) return fail(REVO_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(b->ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
+  return run_pending_edt(b->ctx, b->fs, s);
+}
+
 extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo_pair_result* d_results, void* stream) {
   if (!b || !d_results) return fail(REVO_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(b->ctx->device));
@@ -1191,6 +1221,7 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));  // the keyframes' EDT (side stream of the build)
+  { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; }   // ... or deferred to this launch
   b->last_results = d_results;
   return chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
     return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
@@ -1229,6 +1260,7 @@ extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
   HIPCHECK(hipStreamSynchronize(s));
   if (b->side) HIPCHECK(hipStreamSynchronize(b->side));  // (the keyframes' EDT of the last build)
+  if (b->fs->edt_pending) { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; HIPCHECK(hipStreamSynchronize(s)); }
   // A record with bit 3 carries no pose (its workgroups could not exchange partial sums: device shared with
   // another process): that is an error of the call, not something to find by decoding flags.
   if (b->last_results) {
@@ -1435,6 +1467,7 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
+  { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; }
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
