@@ -169,7 +169,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   if (s.pyr_max_lvl != 0) { *why = "pyr_max_lvl must be 0 (the reference indexes per-level vectors by level)"; return -1; }
   if (L < 1 || L > REVO_L) { *why = "1..6 pyramid levels supported"; return -1; }
   if (s.width <= 0 || s.height <= 0 || s.width > REVO_MAX_WIDTH || s.height > 1024) {
-    *why = "image size must be within 2048 x 1024"; return -1;
+    *why = "image size must be within 2048 x 1024 (and every level's (height + 2) x ceil(width/32) edge bitmap within 155 KB of LDS: 1280 x 960 and 1920 x 640 fit, 1280 x 1024 does not)"; return -1;
   }
   if (s.width % (4 << (L - 1)) || s.height % (1 << (L - 1))) {
     *why = "width must be a multiple of 4*2^(levels-1) and height of 2^(levels-1)"; return -1;
