@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--tum-frames", type=int, default=200, help="frames of --tum-dir to run (0 = all)")
     ap.add_argument("--skip-host-buffers", action="store_true", help="skip the host-buffer (H2D-inclusive) side measurement")
     ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the world-size-1 RCCL group")
+    ap.add_argument("--track-streams", type=int, default=2,
+                    help="streams the tracker launches alternate over (the library keeps REVO_TRACK_DEPTH grids in flight, "
+                         "default 2; more streams than that buy nothing)")
     ap.add_argument("--input-batches", type=int, default=3,
                     help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
                          "than the 256 MB Infinity Cache, so 'resident in HBM' cannot mean 'resident in the last-level cache')")
@@ -340,7 +343,8 @@ def main():
     s_track = torch.cuda.Stream(device=dev)
     # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
     # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
-    s_tracks = [s_track, torch.cuda.Stream(device=dev)] if (not a.no_overlap and not os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else [s_track]
+    n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
+    s_tracks = [s_track] + [torch.cuda.Stream(device=dev) for _ in range(n_tr - 1)]
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev) if nbuf >= 2 else s_track
     torch.cuda.set_stream(s_track)
@@ -537,7 +541,7 @@ def main():
             "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
             "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
                                                         "earlier ones; consecutive tracker grids on %d stream(s), ordered by the library's "
-                                                        "resident gate (at most two in flight)" % (nbuf, a.pairs, len(s_tracks))),
+                                                        "resident gate (at most %s in flight)" % (nbuf, a.pairs, len(s_tracks), os.environ.get("REVO_TRACK_DEPTH", "2"))),
             "batches_in_rotation": nbuf, "pairs_resident": nbuf * a.pairs,
         },
         "roofline": {

@@ -276,9 +276,21 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
 // half-chip grids are resident together, whereas a 75 % grid (round 2) leaves the next one waiting with workgroups that
 // hold CUs and spin (measured, 32 pairs, three batches in rotation: cluster 6 -> 68.5 k, 4 -> 78.2 k, 3 -> 79.2 k frames/s;
 // a launch alone: 0.39 / 0.45 / 0.50 ms).  The in-kernel wait is bounded as a second line of defence.
+// Tracker grids the resident gate keeps in flight per device (REVO_TRACK_DEPTH, default 2; 1 = one at a time, the round-2
+// behaviour; up to 4 for experiments with small clusters: workgroup-time per pair falls with the cluster size -- the
+// exchange and the decision are paid by every member -- but a grid of small clusters only fills a fraction of the chip).
+static int track_depth() {
+  static const int d = [] {
+    const char* e = getenv("REVO_TRACK_SERIAL");
+    if (e && *e && *e != '0') return 1;
+    return env_int("REVO_TRACK_DEPTH", 2, 1, 4);
+  }();
+  return d;
+}
 static int pick_cluster(const revo_ctx* c, int n_pairs) {
   const int resident = c->num_cus * c->blocks_per_cu;
-  int cl = (int)((n_pairs == 1 ? 0.75 : 0.5) * resident) / std::max(1, n_pairs);
+  // a batch grid takes 1/depth of what the device holds: `depth` grids are resident together
+  int cl = (n_pairs == 1 ? (int)(0.75 * resident) : resident / std::max(2, track_depth())) / std::max(1, n_pairs);
   // a single pair: its members share one XCD (blockIdx % 8), i.e. 32 CUs -- 16 workgroups leave half of them
   // to the build kernels of the next frame
   if (n_pairs == 1) cl = std::min(cl, 16);
@@ -304,17 +316,18 @@ static int pick_cluster(const revo_ctx* c, int n_pairs) {
 //     launch n's workgroups fill the CUs that n-1's finished pairs free, and are themselves all resident once n-1 has
 //     drained (192 <= 256 CUs; build kernels finish in finite time).  By induction the older of the two grids is always
 //     fully resident: no cyclic wait.
-// REVO_TRACK_SERIAL=1 restores the round-2 behaviour.  (Other PROCESSES sharing the GPU are outside this library's
+// REVO_TRACK_DEPTH=n (1..4, default 2) sets how many grids may be in flight (launch n waits for launch n-depth to
+// complete); REVO_TRACK_SERIAL=1 = depth 1 = the round-2 behaviour.  (Other PROCESSES sharing the GPU are outside this library's
 // reach: the bounded spin + flag 8 + REVO_ERR_HIP remain the answer there.)
+#define TRACK_MAX_DEPTH 4
 struct TrackChain {
   std::mutex mu;
-  hipEvent_t ev[2] = {nullptr, nullptr};  // completion of the last two launches (ring)
-  hipStream_t st[2] = {nullptr, nullptr};
-  bool has[2] = {false, false};
+  hipEvent_t ev[TRACK_MAX_DEPTH] = {};   // completion of the last `depth` launches (ring)
+  hipStream_t st[TRACK_MAX_DEPTH] = {};
+  bool has[TRACK_MAX_DEPTH] = {};
   int n = 0;                     // launches so far
   unsigned* d_resident = nullptr;
   unsigned started_total = 0;    // workgroups of all launches enqueued so far (the census value once they have all started)
-  int serial = -1;
 };
 static TrackChain g_chain[64];
 // launch(): enqueues the tracker grid on s and returns its workgroup count
@@ -322,19 +335,18 @@ template <typename F>
 static int chained_track_launch(int device, hipStream_t s, F&& launch) {
   TrackChain& ch = g_chain[device & 63];
   std::lock_guard<std::mutex> lk(ch.mu);
-  if (ch.serial < 0) { const char* e = getenv("REVO_TRACK_SERIAL"); ch.serial = (e && *e && *e != '0') ? 1 : 0; }
+  const int depth = track_depth();
   if (!ch.ev[0]) {
-    HIPCHECK(hipEventCreateWithFlags(&ch.ev[0], hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&ch.ev[1], hipEventDisableTiming));
+    for (int i = 0; i < TRACK_MAX_DEPTH; ++i) HIPCHECK(hipEventCreateWithFlags(&ch.ev[i], hipEventDisableTiming));
     HIPCHECK(hipMalloc((void**)&ch.d_resident, sizeof(unsigned)));
     HIPCHECK(hipMemset(ch.d_resident, 0, sizeof(unsigned)));
   }
-  const int cur = ch.n & 1, prev = cur ^ 1;  // slot `cur` holds launch n-2, slot `prev` launch n-1
-  if (ch.has[cur] && ch.st[cur] != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev[cur], 0));  // n-2 complete
-  if (ch.has[prev] && ch.st[prev] != s) {
-    if (ch.serial) HIPCHECK(hipStreamWaitEvent(s, ch.ev[prev], 0));                     // n-1 complete (round-2 behaviour)
-    else launch_track_gate(ch.d_resident, ch.started_total, s);                         // n-1 fully resident
-  }
+  // slot `cur` holds launch n-depth (it must be COMPLETE: at most `depth` grids in flight), slot `prev` launch n-1 (it must
+  // be fully RESIDENT: only the newest grid is ever partially on the chip, every older one holds all its CUs and finishes
+  // whatever arrives -- no cyclic wait at any depth).  With depth 1 the two coincide: one grid at a time.
+  const int cur = ch.n % depth, prev = (ch.n + depth - 1) % depth;
+  if (ch.has[cur] && ch.st[cur] != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev[cur], 0));
+  if (depth > 1 && ch.has[prev] && ch.st[prev] != s) launch_track_gate(ch.d_resident, ch.started_total, s);
   const int n_wg = launch(ch.d_resident);
   HIPCHECK(hipGetLastError());              // (a refused launch adds nothing to the census: the next gate must not wait for it)
   ch.started_total += (unsigned)n_wg;
