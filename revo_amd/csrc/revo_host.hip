@@ -78,7 +78,7 @@ struct FrameSet {
   // (batches) the keyframes' EDT has been DEFERRED to whoever needs it first -- normally the tracker launch of the batch, on
   // the tracker's stream: the build stream is the critical one of the pipelined step and the tracker streams have slack
   std::mutex edt_mu;
-  bool edt_pending = false;
+  std::atomic<bool> edt_pending{false};  // set by a batch build, cleared under edt_mu by whoever runs the EDT
   int edt_count = 0;              // keyframes: frames 0, 2, 4, ...
   hipEvent_t ev_free = nullptr;   // recorded on the tracker stream when the set goes back to the pool
   bool has_ready = false, has_free = false;
