@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--track-streams", type=int, default=2,
                     help="streams the tracker launches alternate over (the library keeps REVO_TRACK_DEPTH grids in flight, "
                          "default 2; more streams than that buy nothing)")
+    ap.add_argument("--build-streams", type=int, default=1, help="experiment: builds of consecutive steps alternate over this many streams")
     ap.add_argument("--input-batches", type=int, default=3,
                     help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
                          "than the 256 MB Infinity Cache, so 'resident in HBM' cannot mean 'resident in the last-level cache')")
@@ -347,6 +348,8 @@ def main():
     s_tracks = [s_track] + [torch.cuda.Stream(device=dev) for _ in range(n_tr - 1)]
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev) if nbuf >= 2 else s_track
+    # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
+    s_builds = [s_build] + [torch.cuda.Stream(device=dev) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
     torch.cuda.set_stream(s_track)
     stream = s_track.cuda_stream
     assert stream != 0 and s_build.cuda_stream != 0
@@ -365,11 +368,12 @@ def main():
         d_out = d_ress[counter[0] % len(d_ress)]
         j_in = counter[0] % nin                      # the input batches rotate: step t reads input t mod nin
         s_tr = s_tracks[counter[0] % len(s_tracks)]
+        s_bld = s_builds[counter[0] % len(s_builds)]
         counter[0] += 1
         if nbuf >= 2:
-            s_build.wait_event(ev_tracked[k])        # batch k free again (its previous tracker is done)
-            bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_build.cuda_stream, borrow_depth=True)
-            ev_built[k].record(s_build)
+            s_bld.wait_event(ev_tracked[k])          # batch k free again (its previous tracker is done)
+            bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_bld.cuda_stream, borrow_depth=True)
+            ev_built[k].record(s_bld)
             s_tr.wait_event(ev_built[k])
             if timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
                 e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
