@@ -221,3 +221,16 @@ def test_bench_rank_plumbing_world2_under_torchrun():
     rec = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(rec) == 1  # rank 0 only
     _check_dry_run_line(rec[0], 2, 3, 2)
+
+
+def test_ab_bench_variant_specs():
+    """profiles/ab_bench.py: NAME=SPEC[@bench args] -> (name, environment, extra arguments)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ab_bench", os.path.join(ROOT, "profiles", "ab_bench.py"))
+    ab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ab)
+    assert ab.parse_variant("base=") == ("base", {}, [])
+    name, env, extra = ab.parse_variant("d3=REVO_TRACK_DEPTH=3,profiles/build/x.so@--buffers 4 --track-streams 3")
+    assert name == "d3" and env["REVO_TRACK_DEPTH"] == "3" and env["REVO_HIP_SO"].endswith("profiles/build/x.so")
+    assert os.path.isabs(env["REVO_HIP_SO"]) and extra == ["--buffers", "4", "--track-streams", "3"]
+    assert ab.parse_variant("b2=@--build-streams 2") == ("b2", {}, ["--build-streams", "2"])
