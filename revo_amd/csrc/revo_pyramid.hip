@@ -1996,24 +1996,26 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
   for (int k = 0; k < grp; ++k) above = max(above, s_last[k * ncols + col]);
   for (int k = ngroups - 1; k > grp; --k) below = min(below, s_first[k * ncols + col]);
   uint16_t* gd = reinterpret_cast<uint16_t*>(pl.scratch[l]) + (size_t)f * lv.npix;  // vertical distance, 0xffff = no edge in the column
+  // walking down the segment: the distance to the nearest edge above grows by one per row and drops to 0 on an edge; the one
+  // below is ffs on what is left of the mask, or the carry from the groups below.  "No edge" is a distance beyond any height
+  // (the rows of a level are <= 1024), so the sums below cannot wrap and everything >= 0xffff is written as 0xffff.
+  const int FAR = 1 << 20;
+  int du = (above <= -EDT_INF) ? FAR : (yb - above);      // of row yb - 1, plus one
+  const int dbelow = (below >= EDT_INF) ? FAR : (below - yb);
   for (int y = yb; y < ye; ++y) {
     const int k = y - yb;
-    const unsigned lo = em & (0xffffffffu >> (31 - k));  // bits 0..k: edges at or above y (inside the segment)
     const unsigned hi = em >> k;                          // bit 0 = row y: edges at or below y
-    const int up = lo ? yb + 31 - __clz(lo) : above;
-    const int dn = hi ? y + __ffs(hi) - 1 : below;
-    const int d_up = (up <= -EDT_INF) ? EDT_INF : (y - up);
-    const int d_dn = (dn >= EDT_INF) ? EDT_INF : (dn - y);
-    const int m = min(d_up, d_dn);
-    gd[(size_t)y * lv.w + x] = (uint16_t)(m >= EDT_INF ? 0xffff : m);  // height <= 1024
+    du = (hi & 1u) ? 0 : du;
+    const int dn = hi ? __ffs(hi) - 1 : dbelow - k;
+    const int m = min(du, dn);
+    gd[(size_t)y * lv.w + x] = (uint16_t)(m >= 0xffff ? 0xffff : m);
+    du += 1;
   }
 }
 
-// Rows: a workgroup takes whole rows worth ~EDT_ROW_PX pixels (2 rows of 640, 16 of 80: every lane has a pixel;
-// one workgroup per row left 70 % of the lanes of the small levels idle), squares the vertical distances into LDS
-// rows padded with "no edge" on both sides as far as the search can reach, and every pixel searches outwards
-//      d2(x) = min_d  d^2 + min(g2[x - d], g2[x + d]),     four distances per trip, until d^2 >= best
-// with no bounds checks (round 1: two compares + two selects per sample, 30 M VALU + 28 M SALU per launch).
+// Rows: a workgroup takes whole rows worth ~EDT_ROW_PX pixels (2 rows of 640, 16 of 80: every lane has a pixel), squares the
+// vertical distances into LDS rows padded with "no edge" on both sides as far as the search can reach, and every pixel searches
+//      d2(x) = min_d  d^2 + min(g2[x - d], g2[x + d]),     four distances per trip, until d^2 >= best      (no bounds checks)
 // sqrtf of an integer-valued float in [0, 2^24): v_sqrt_f32 (within 1 ulp) and the +-1 ulp correction of the compiler's own
 // sqrtf expansion, without its scaling of tiny inputs and its inf / nan / zero classification (x = 0 falls through both
 // corrections: the residual of the lower neighbour is NaN, that of the upper one is not positive).  Same instructions on the
