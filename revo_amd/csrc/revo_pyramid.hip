@@ -1996,24 +1996,39 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
   for (int k = 0; k < grp; ++k) above = max(above, s_last[k * ncols + col]);
   for (int k = ngroups - 1; k > grp; --k) below = min(below, s_first[k * ncols + col]);
   uint16_t* gd = reinterpret_cast<uint16_t*>(pl.scratch[l]) + (size_t)f * lv.npix;  // vertical distance, 0xffff = no edge in the column
+  // walking down the segment: the distance to the nearest edge above grows by one per row and drops to 0 on an edge; the one
+  // below is ffs on what is left of the mask, or the carry from the groups below.  "No edge" is a distance beyond any height
+  // (the rows of a level are <= 1024), so the sums below cannot wrap and everything >= 0xffff is written as 0xffff.
+  const int FAR = 1 << 20;
+  int du = (above <= -EDT_INF) ? FAR : (yb - above);      // of row yb - 1, plus one
+  const int dbelow = (below >= EDT_INF) ? FAR : (below - yb);
   for (int y = yb; y < ye; ++y) {
     const int k = y - yb;
-    const unsigned lo = em & (0xffffffffu >> (31 - k));  // bits 0..k: edges at or above y (inside the segment)
     const unsigned hi = em >> k;                          // bit 0 = row y: edges at or below y
-    const int up = lo ? yb + 31 - __clz(lo) : above;
-    const int dn = hi ? y + __ffs(hi) - 1 : below;
-    const int d_up = (up <= -EDT_INF) ? EDT_INF : (y - up);
-    const int d_dn = (dn >= EDT_INF) ? EDT_INF : (dn - y);
-    const int m = min(d_up, d_dn);
-    gd[(size_t)y * lv.w + x] = (uint16_t)(m >= EDT_INF ? 0xffff : m);  // height <= 1024
+    du = (hi & 1u) ? 0 : du;
+    const int dn = hi ? __ffs(hi) - 1 : dbelow - k;
+    const int m = min(du, dn);
+    gd[(size_t)y * lv.w + x] = (uint16_t)(m >= 0xffff ? 0xffff : m);
+    du += 1;
   }
 }
 
-// Rows: a workgroup takes whole rows worth ~EDT_ROW_PX pixels (2 rows of 640, 16 of 80: every lane has a pixel;
-// one workgroup per row left 70 % of the lanes of the small levels idle), squares the vertical distances into LDS
-// rows padded with "no edge" on both sides as far as the search can reach, and every pixel searches outwards
-//      d2(x) = min_d  d^2 + min(g2[x - d], g2[x + d]),     four distances per trip, until d^2 >= best
-// with no bounds checks (round 1: two compares + two selects per sample, 30 M VALU + 28 M SALU per launch).
+// Rows: a workgroup takes whole rows worth ~EDT_ROW_PX pixels (2 rows of 640, 16 of 80: every lane has a pixel), squares the
+// vertical distances into LDS rows padded with "no edge" on both sides as far as the search can reach, and every pixel searches
+//      d2(x) = min_d  d^2 + min(g2[x - d], g2[x + d]),     four distances per trip, until d^2 >= best      (no bounds checks)
+// sqrtf of an integer-valued float in [0, 2^24): v_sqrt_f32 (within 1 ulp) and the +-1 ulp correction of the compiler's own
+// sqrtf expansion, without its scaling of tiny inputs and its inf / nan / zero classification (x = 0 falls through both
+// corrections: the residual of the lower neighbour is NaN, that of the upper one is not positive).  Same instructions on the
+// same values as sqrtf(x) for x >= 1: correctly rounded.
+__device__ __forceinline__ float sqrt_rn_int(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const unsigned si = __float_as_uint(s);
+  const float sd = __uint_as_float(si - 1u), su = __uint_as_float(si + 1u);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  float r = (rd <= 0.0f) ? sd : s;
+  r = (ru > 0.0f) ? su : r;
+  return r;
+}
 __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int f0, int fstride) {
   extern __shared__ int s_g2[];
   const int f = f0 + blockIdx.z * fstride;
@@ -2024,24 +2039,28 @@ __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int
   const int nr = min(lv.edt_rows, lv.h - y0);
   const int pad = w + 4, pitch = w + 2 * pad;  // the search stops at d < w (+3 for the trip): never leaves the padding
   const uint16_t* gd = reinterpret_cast<const uint16_t*>(pl.scratch[l]) + (size_t)f * lv.npix + (size_t)y0 * w;
-  const float inv_pitch = 1.0f / (float)pitch, inv_w = 1.0f / (float)w;
-  for (int i = threadIdx.x; i < nr * pitch; i += 256) {
-    int r = (int)(((float)i + 0.5f) * inv_pitch);
-    r += (r + 1) * pitch <= i ? 1 : (r * pitch > i ? -1 : 0);
-    const int c = i - r * pitch - pad;
-    int v = EDT_INF;
-    if (c >= 0 && c < w) {
-      const int d = gd[r * w + c];
-      v = d == 0xffff ? EDT_INF : d * d;
+  // LDS rows: [pad "no edge"][w squared vertical distances][pad "no edge"].  Row by row, no index division (the flattened
+  // fill with its divisions was 43 % of this kernel's VALU instructions): the pads are constant 16-byte stores (widths are
+  // multiples of 4, so pad, pitch and every row start are too), the data four pixels per lane from one 8-byte load.
+  const int4 inf4 = make_int4(EDT_INF, EDT_INF, EDT_INF, EDT_INF);
+  const int padq = pad >> 2, wq = w >> 2;
+  for (int r = 0; r < nr; ++r) {
+    int4* row4 = reinterpret_cast<int4*>(s_g2 + r * pitch);
+    for (int i = threadIdx.x; i < padq; i += 256) { row4[i] = inf4; row4[padq + wq + i] = inf4; }
+    const uint2* src = reinterpret_cast<const uint2*>(gd + r * w);
+    for (int i = threadIdx.x; i < wq; i += 256) {
+      const uint2 q = src[i];
+      const int d0 = (int)(q.x & 0xffffu), d1 = (int)(q.x >> 16), d2 = (int)(q.y & 0xffffu), d3 = (int)(q.y >> 16);
+      row4[padq + i] = make_int4(d0 == 0xffff ? EDT_INF : __mul24(d0, d0), d1 == 0xffff ? EDT_INF : __mul24(d1, d1),
+                                 d2 == 0xffff ? EDT_INF : __mul24(d2, d2), d3 == 0xffff ? EDT_INF : __mul24(d3, d3));
     }
-    s_g2[i] = v;
   }
   __syncthreads();
   float* dt = pl.dt[l] + (size_t)f * lv.npix + (size_t)y0 * w;
+  // pixel p = r * w + x, p += 256 per trip: (r, x) advance by (256 / w, 256 % w) with one carry -- one division per thread
+  const int dq = 256 / w, dr = 256 - dq * w;
+  int r = threadIdx.x / w, x = threadIdx.x - r * w;
   for (int p = threadIdx.x; p < nr * w; p += 256) {
-    int r = (int)(((float)p + 0.5f) * inv_w);
-    r += (r + 1) * w <= p ? 1 : (r * w > p ? -1 : 0);
-    const int x = p - r * w;
     const int* c = s_g2 + r * pitch + pad + x;
     int best = c[0];
     for (int d = 1; d < w && d * d < best; d += 4) {
@@ -2053,7 +2072,9 @@ __global__ void __launch_bounds__(256) k_edt_rows(PyrGeom g, FramePlanes pl, int
       }
       best = m;
     }
-    dt[p] = best >= EDT_INF ? sqrtf(1e15f) : sqrtf((float)best);
+    dt[p] = best >= EDT_INF ? sqrtf(1e15f) : sqrt_rn_int((float)best);
+    x += dr; r += dq;
+    if (x >= w) { x -= w; ++r; }
   }
 }
 
