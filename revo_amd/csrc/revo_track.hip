@@ -601,6 +601,70 @@ __device__ __forceinline__ void error_block(const Cand* cand, const f4v* preg, g
   for (int i = first + TRACK_MAXP * stride; i < N; i += stride) error_points<NE>(pts[i], dtm, R, T, cam, ed, filt, huber, e + 3);
 }
 
+// Candidate 0 in full and NE error-only retries of the SAME point in one go.  A retry is a shorter step from the same pose
+// (optimizer.cpp:291-304: same normal equations, larger damping); near convergence -- where the rejections are -- it lands on
+// candidate 0's pixel or a direct neighbour, and then its four DT samples are already in the 12-sample patch: they are
+// picked out of registers instead of costing the vector L1 another ~27 tag lookups per gather.  Lanes whose retry moved
+// farther gather as before, under the exec mask (a gather is priced by the distinct lines of its ACTIVE lanes).  Same
+// values from the same addresses, same accumulation order per candidate: the sums do not change by a bit.
+template <int NE>
+__device__ __forceinline__ void fused_point(const f4v p, gf32p dtm, const float* R0, const float* T0, const float (*R)[9],
+                                            const float (*T)[3], const Cam& c, float ed, bool filt, float huber, float* acc,
+                                            float* e) {
+  const PtState s0 = project_point(p, R0, T0, c, true);
+  PtState s[NE];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) s[j] = project_point(p, R[j], T[j], c, true);
+  const DtPatch q = load_patch(dtm, c.w, s0.ix, s0.iy);
+  float g00[NE], g10[NE], g01[NE], g11[NE];
+  int ddx[NE], ddy[NE];
+  bool hit[NE];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    ddx[j] = s[j].ix - s0.ix;
+    ddy[j] = s[j].iy - s0.iy;
+    hit[j] = (ddy[j] == 0 && ddx[j] >= -1 && ddx[j] <= 1) || (ddx[j] == 0 && (ddy[j] == 1 || ddy[j] == -1));
+    g00[j] = g10[j] = g01[j] = g11[j] = 0.0f;
+    if (!hit[j]) {
+      gf32p t = dtm + s[j].iy * c.w + s[j].ix;
+      g00[j] = t[0]; g10[j] = t[1]; g01[j] = t[c.w]; g11[j] = t[c.w + 1];
+    }
+  }
+  accumulate_point(s0, q, c.fx, c.fy, ed, filt, huber, acc, e);
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    float d00 = g00[j], d10 = g10[j], d01 = g01[j], d11 = g11[j];
+    if (hit[j]) {
+      const bool same_row = ddy[j] == 0, up = ddy[j] < 0, left = ddx[j] < 0, mid = ddx[j] == 0;
+      // rows iy0 / iy0+1 shifted by ddx, or rows iy0-1 / iy0, or rows iy0+1 / iy0+2 (ddx == 0)
+      d00 = same_row ? (left ? q.b0 : (mid ? q.b1 : q.b2)) : (up ? q.a0 : q.c1);
+      d10 = same_row ? (left ? q.b1 : (mid ? q.b2 : q.b3)) : (up ? q.a1 : q.c2);
+      d01 = same_row ? (left ? q.c0 : (mid ? q.c1 : q.c2)) : (up ? q.b1 : q.d0);
+      d11 = same_row ? (left ? q.c1 : (mid ? q.c2 : q.c3)) : (up ? q.b2 : q.d1);
+    }
+    const float dxdy = s[j].dx * s[j].dy;
+    const float w11 = dxdy, w01 = s[j].dy - dxdy, w10 = s[j].dx - dxdy, w00 = ((1.0f - s[j].dx) - s[j].dy) + dxdy;
+    float res = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
+    const bool good = s[j].valid && !(res > ed && filt);
+    if (!good) res = 0.0f;
+    const float wr = (res <= huber) ? 1.0f : revo_div(huber, res);
+    accumulate_error(res, wr, good, e + 3 + 3 * j);
+  }
+}
+
+template <int NE>
+__device__ __forceinline__ void fused_block(const Cand* cand, const f4v* preg, gf4p pts, int first, int stride, int N, gf32p dtm,
+                                            const Cam& cam, float ed, bool filt, float huber, float* acc, float* e) {
+  float R0[9], T0[3], R[NE][9], T[NE][3];
+  load_pose(cand[0], R0, T0);
+#pragma unroll
+  for (int j = 0; j < NE; ++j) load_pose(cand[1 + j], R[j], T[j]);
+#pragma unroll
+  for (int k = 0; k < TRACK_MAXP; ++k)
+    if (first + k * stride < N) fused_point<NE>(preg[k], dtm, R0, T0, R, T, cam, ed, filt, huber, acc, e);
+  for (int i = first + TRACK_MAXP * stride; i < N; i += stride) fused_point<NE>(pts[i], dtm, R0, T0, R, T, cam, ed, filt, huber, acc, e);
+}
+
 // ---- the kernel ---------------------------------------------------------------
 #define TRACK_OCC __attribute__((amdgpu_waves_per_eu(TRACK_WAVES_PER_EU, TRACK_WAVES_PER_EU)))
 // ONE: the single pair of the sequential API arrives by value in the kernel-argument segment (no
@@ -778,7 +842,10 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       float acc[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-      {  // candidate 0 in full: residual + Jacobian + normal equations
+      if (pc.ncand == 4) fused_block<3>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, acc, e);
+      else if (pc.ncand == 3) fused_block<2>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, acc, e);
+      else if (pc.ncand == 2) fused_block<1>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, acc, e);
+      else {  // a single candidate in full: residual + Jacobian + normal equations
         float R[9], T[3];
         load_pose(s_cand[pb][0], R, T);
 #pragma unroll
@@ -787,10 +854,6 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
         for (int i = first + TRACK_MAXP * stride; i < N; i += stride) full_point(pts[i], dtm, R, T, cam, ed, filt, huber, acc, e);
       }
       PROF_MARK(te1);
-      // the speculative retries: error only
-      if (pc.ncand == 4) error_block<3>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
-      else if (pc.ncand == 3) error_block<2>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
-      else if (pc.ncand == 2) error_block<1>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, e);
       PROF_MARK(te2);
       reduce32(acc, lane);
       reduce16(e, lane);
