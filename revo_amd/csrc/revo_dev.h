@@ -39,6 +39,7 @@ struct PyrGeom {
   int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
   int nms_px;          // pixels per thread of the Canny NMS kernel the block counts below were made for (8 or 4)
   int total_bands, any_banded;  // hysteresis bands of all levels; 1 if some level has more than one
+  int hyst_force;      // -1: banded hysteresis where a level does not fit one workgroup (default); 1 / 0: always / never (REVO_HYST_BANDED)
   int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
@@ -140,8 +141,8 @@ void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride
 // workgroup adds 1 when it starts), nullptr = no census
 int launch_track(const PairDesc* d_descs, const TrackParams& prm, revo_pair_result* d_out, EvalOut* d_eval,
                  int n_pairs, unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* d_resident, hipStream_t s);
-// waits on the device until the census counter has reached `want`
-void launch_track_gate(const unsigned* d_resident, unsigned want, hipStream_t s);
+// waits on the device until the census counter d_resident[0] has reached `want`; a gate that gives up counts itself in d_resident[1]
+void launch_track_gate(unsigned* d_resident, unsigned want, hipStream_t s);
 // seq_ptr (pinned host memory, may be null): receives seq_val after the result record has been written
 int launch_track_one(const PairDesc& desc, const TrackParams& prm, revo_pair_result* out, EvalOut* eval_out,
                      unsigned long long* d_mail, unsigned* epoch_io, int cluster, unsigned* seq_ptr, unsigned seq_val,

@@ -80,6 +80,11 @@ struct FrameSet {
   std::mutex edt_mu;
   std::atomic<bool> edt_pending{false};  // set by a batch build, cleared under edt_mu by whoever runs the EDT
   int edt_count = 0;              // keyframes: frames 0, 2, 4, ...
+  // whoever ran the deferred EDT recorded this on ITS stream: consumers (and the next build into these planes) on any other
+  // stream order themselves behind it (`edt_pending == false` alone says "enqueued somewhere", not "visible here")
+  hipEvent_t ev_edt = nullptr;
+  hipStream_t edt_stream = nullptr;
+  bool has_edt = false;
   hipEvent_t ev_free = nullptr;   // recorded on the tracker stream when the set goes back to the pool
   bool has_ready = false, has_free = false;
 };
@@ -109,7 +114,7 @@ struct revo_ctx {
   PairDesc* h_desc;
   revo_pair_result* h_res;      // [3]: slots 0/1 = the VO driver's look-ahead launches, slot 2 = the public single-pair calls
   EvalOut* h_eval;
-  unsigned* h_seq;              // [3] pinned: sequence words the kernels write after their results (2 tracker slots, vote)
+  unsigned* h_seq;              // [4] pinned: sequence words the kernels write after their results (slots 0/1: the VO driver's look-ahead launches, 2: the public single-pair calls)
   unsigned seq_next = 1;
   unsigned long long* d_mail;   // cluster mailbox of the single-pair path
   unsigned mail_epoch = 0;      // next free epoch window of d_mail (launch_track_one)
@@ -150,6 +155,11 @@ struct revo_batch {
   hipStream_t side = nullptr;                      // the EDT of the keyframes runs here, next to the edge lists
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev0, ev1, ev_upload;
+  // the batch's last tracker grid: a later launch of the SAME batch on another stream shares its mailbox and descriptors,
+  // and the next build rewrites what it reads -- both order themselves behind this event
+  hipEvent_t ev_trk = nullptr;
+  hipStream_t trk_stream = nullptr;
+  bool has_trk = false;
   const revo_pair_result* last_results = nullptr;  // device records of the last track launch (revo_batch_sync decodes their flags)
   revo_pair_result* h_flags = nullptr;             // pinned scratch for that
 };
@@ -175,6 +185,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     *why = "width must be a multiple of 4*2^(levels-1) and height of 2^(levels-1)"; return -1;
   }
   g->n_levels = L;
+  { const char* e = getenv("REVO_HYST_BANDED"); g->hyst_force = (e && *e) ? (*e != '0' ? 1 : 0) : -1; }
   g->nms_px = env_int("REVO_NMS_PX", 4, 4, 8) == 8 ? 8 : 4;
   g->depth_min = s.depth_min; g->depth_max = s.depth_max;
   // cv::Canny with L2gradient: low/high swapped if needed, squared (imgpyramidrgbd.cpp:184)
@@ -290,7 +301,9 @@ static int track_depth() {
 static int pick_cluster(const revo_ctx* c, int n_pairs) {
   const int resident = c->num_cus * c->blocks_per_cu;
   // a batch grid takes 1/depth of what the device holds: `depth` grids are resident together
-  int cl = (n_pairs == 1 ? (int)(0.75 * resident) : resident / std::max(2, track_depth())) / std::max(1, n_pairs);
+  // (depth 1 = one grid at a time: the round-2 shape, 75 % of the chip)
+  const int share = n_pairs == 1 || track_depth() == 1 ? (int)(0.75 * resident) : resident / track_depth();
+  int cl = share / std::max(1, n_pairs);
   // a single pair: its members share one XCD (blockIdx % 8), i.e. 32 CUs -- 16 workgroups leave half of them
   // to the build kernels of the next frame
   if (n_pairs == 1) cl = std::min(cl, 16);
@@ -338,8 +351,8 @@ static int chained_track_launch(int device, hipStream_t s, F&& launch) {
   const int depth = track_depth();
   if (!ch.ev[0]) {
     for (int i = 0; i < TRACK_MAX_DEPTH; ++i) HIPCHECK(hipEventCreateWithFlags(&ch.ev[i], hipEventDisableTiming));
-    HIPCHECK(hipMalloc((void**)&ch.d_resident, sizeof(unsigned)));
-    HIPCHECK(hipMemset(ch.d_resident, 0, sizeof(unsigned)));
+    HIPCHECK(hipMalloc((void**)&ch.d_resident, 2 * sizeof(unsigned)));  // [0] census, [1] gates that timed out
+    HIPCHECK(hipMemset(ch.d_resident, 0, 2 * sizeof(unsigned)));
   }
   // slot `cur` holds launch n-depth (it must be COMPLETE: at most `depth` grids in flight), slot `prev` launch n-1 (it must
   // be fully RESIDENT: only the newest grid is ever partially on the chip, every older one holds all its CUs and finishes
@@ -355,6 +368,15 @@ static int chained_track_launch(int device, hipStream_t s, F&& launch) {
   ch.st[cur] = s;
   ch.n += 1;
   return REVO_OK;
+}
+// how many resident gates of this device gave up waiting so far (0 in a healthy process); -1: no tracker launch yet
+extern "C" int revo_debug_gate_timeouts_(int device) {
+  TrackChain& ch = g_chain[device & 63];
+  std::lock_guard<std::mutex> lk(ch.mu);
+  if (!ch.d_resident) return -1;
+  unsigned v = 0;
+  if (hipMemcpy(&v, ch.d_resident + 1, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (int)v;
 }
 static size_t mail_bytes(int n_pairs, int cluster) { return sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * TRACK_NVAL; }
 
@@ -414,6 +436,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
   }
   HIPCHECK(hipEventCreateWithFlags(&fs->ev_ready, hipEventDisableTiming));
   HIPCHECK(hipEventCreateWithFlags(&fs->ev_free, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&fs->ev_edt, hipEventDisableTiming));
   // counts start at zero so an accessor on a not-yet-built pyramid is well defined
   hipMemsetAsync(fs->p.npts, 0, sizeof(int) * REVO_L * B, c->stream);
   HIPCHECK(hipStreamSynchronize(c->stream));
@@ -427,6 +450,7 @@ static void frameset_destroy(FrameSet* fs) {
   if (fs->h_depth) hipHostFree(fs->h_depth);
   if (fs->ev_ready) hipEventDestroy(fs->ev_ready);
   if (fs->ev_free) hipEventDestroy(fs->ev_free);
+  if (fs->ev_edt) hipEventDestroy(fs->ev_edt);
   delete fs;
 }
 
@@ -454,6 +478,7 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
 // depend on the edge maps, not on each other, and all four are latency-bound with idle CUs around them: the EDT runs on a
 // side stream next to the lists (fork after fillInEdges, join before the batch's stream goes on).
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s);
+static int batch_wait_tracker(revo_batch* b, hipStream_t s);
 
 // ------------------------------------------------------------------ context --
 static void ctx_free(revo_ctx* c);
@@ -576,11 +601,24 @@ extern "C" int revo_ctx_camera(const revo_ctx* c, int lvl, float out6[6]) {
 // Runs a deferred keyframe EDT of the set on stream s (which is first ordered behind the build).
 static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
   std::lock_guard<std::mutex> lk(fs->edt_mu);
-  if (!fs->edt_pending) return REVO_OK;
+  if (!fs->edt_pending) {
+    // already enqueued by an earlier consumer: a consumer on ANOTHER stream must still wait for it
+    if (fs->has_edt && fs->edt_stream != s) HIPCHECK(hipStreamWaitEvent(s, fs->ev_edt, 0));
+    return REVO_OK;
+  }
   if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, fs->ev_ready, 0));
   launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
   HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(fs->ev_edt, s));
+  fs->has_edt = true;
+  fs->edt_stream = s;
   fs->edt_pending = false;
+  return REVO_OK;
+}
+// the next build into a set's planes: the deferred EDT of the previous build may still be reading its edge maps on another stream
+static int wait_edt_before_rebuild(FrameSet* fs, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(fs->edt_mu);
+  if (fs->has_edt && fs->edt_stream != s) HIPCHECK(hipStreamWaitEvent(s, fs->ev_edt, 0));
   return REVO_OK;
 }
 static int wait_ready(revo_ctx* c, const revo_pyr* p) {
@@ -588,8 +626,8 @@ static int wait_ready(revo_ctx* c, const revo_pyr* p) {
   // (revo_batch_build records the event) -- either way the consumer stream is ordered behind the build
   if (p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
   if (p->fs->has_aux) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_aux, 0));
-  if (p->fs->edt_pending) return run_pending_edt(c, p->fs, c->stream);  // an accessor / single-pair call on a batch view came first
-  return REVO_OK;
+  // an accessor / single-pair call on a batch view: runs the deferred EDT if it is still pending, waits for it otherwise
+  return run_pending_edt(c, p->fs, c->stream);
 }
 
 static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_stride, const void* depth,
@@ -1111,6 +1149,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreate(&b->ev0)); HIPCHECK(hipEventCreate(&b->ev1));
   HIPCHECK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&b->ev_trk, hipEventDisableTiming));
   // REVO_BUILD_FORK=1: the keyframes' EDT on a side stream next to the edge-list kernels.  Off by default: when the two
   // really run concurrently (their streams on different hardware queues) the pipelined step collapses (GPU_MAX_HW_QUEUES=8:
   // 78.5 k -> 47.4 k frames/s), and with HIP's default four queues, where they mostly share a queue, it gains nothing
@@ -1144,11 +1183,23 @@ extern "C" void revo_batch_destroy(revo_batch* b) {
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev_upload) hipEventDestroy(b->ev_upload);
+  if (b->ev_trk) hipEventDestroy(b->ev_trk);
   if (b->stream) hipStreamDestroy(b->stream);
   frameset_destroy(b->fs);
   revo_ctx* c = b->ctx;
   delete b;
   ctx_unref(c);
+}
+
+static int batch_wait_tracker(revo_batch* b, hipStream_t s) {
+  if (b->has_trk && b->trk_stream != s) HIPCHECK(hipStreamWaitEvent(s, b->ev_trk, 0));
+  return REVO_OK;
+}
+static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
+  HIPCHECK(hipEventRecord(b->ev_trk, s));
+  b->has_trk = true;
+  b->trk_stream = s;
+  return REVO_OK;
 }
 
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
@@ -1183,8 +1234,11 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   // (Splitting the batch into slices of pairs on 2 / 4 streams was measured in both rounds: no gain in round 1,
   // and with the round-2 kernels the step goes from 0.64 ms to 0.73 / 0.84 ms next to a tracker -- the build
   // kernels are throughput-limited, smaller launches only add tails.)
-  b->last_results = nullptr;  // records of an earlier launch are the caller's business again
+  // (last_results stays: a caller that pipelines track_only(k) -> build(k) -> sync still gets the flag-8 check of launch k;
+  // the result buffer must stay valid until revo_batch_sync or the next revo_batch_track_only)
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));  // the previous build's EDT still reads these planes
+  { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }     // ... or its deferred EDT, on whichever stream ran it
+  { int rc = batch_wait_tracker(b, s); if (rc) return rc; }              // ... and its tracker grid still reads lists and DT planes
   // (Measured and not kept: the two halves of the batch as two concurrent kernel chains -- 78.4 k -> 70.5 k frames/s.)
   enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
@@ -1228,6 +1282,8 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (!b || !d_results) return fail(REVO_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  // an earlier grid of this batch on another stream still reads the descriptors and the mailbox
+  { int rc0 = batch_wait_tracker(b, s); if (rc0) return rc0; }
   int rc = batch_upload_init(b, h_init_RT, s);
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
@@ -1235,9 +1291,11 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));  // the keyframes' EDT (side stream of the build)
   { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; }   // ... or deferred to this launch
   b->last_results = d_results;
-  return chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
+  rc = chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
     return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
   });
+  if (rc) return rc;
+  return batch_mark_tracker(b, s);
 }
 
 // Same as revo_batch_build for raw 16-bit depth (the reference's on-disk format): the conversion
@@ -1248,8 +1306,9 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   if (!(depth_scale_factor > 0.0)) return fail(REVO_ERR_INVALID_ARG, "depth_scale_factor must be positive");
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-  b->last_results = nullptr;
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
+  { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }
+  { int rc = batch_wait_tracker(b, s); if (rc) return rc; }
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
@@ -1474,6 +1533,8 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   if (!b || !d_results || !ms_mean || reps <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
   HIPCHECK(hipSetDevice(b->ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+  // an earlier grid of this batch on another stream still reads the descriptors and the mailbox
+  { int rc0 = batch_wait_tracker(b, s); if (rc0) return rc0; }
   int rc = batch_upload_init(b, h_init_RT, s);
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
@@ -1494,5 +1555,5 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
     total += ms;
   }
   *ms_mean = total / (float)reps;
-  return REVO_OK;
+  return batch_mark_tracker(b, s);
 }

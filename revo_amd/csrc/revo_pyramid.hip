@@ -1634,7 +1634,8 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
       if (i1 < nslots) s_cnt[i1] = run + c0;
       __syncthreads();
     }
-    if (tid == 0 && strip == (lv.w + CW_COLS - 1) / CW_COLS - 1) pl.npts[f * REVO_L + l] = base + total;
+    // (npts is NOT stored here: k_tile_count wrote the same count during the build, and this accessor-only walk may run
+    // while a batch tracker on another stream reads it -- ADVICE r03)
     const bool staged = total <= CW_STAGE;
     float4* out = pl.pts[l] + (size_t)f * lv.npix;
     if (x < lv.w) {
@@ -2207,8 +2208,7 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   // then builds in 1.25 ms instead of 1.75 ms with the flood fill; at 640x480 the four kernels of the banded path take as
   // long as the one workgroup per (level, frame) (78 vs 79 us per 64 frames: measured, profiles/r03_hyst_banding.txt), so
   // that size keeps the single kernel.  REVO_HYST_BANDED=1 / 0 forces either.
-  static int force = -2;
-  if (force == -2) { const char* e = getenv("REVO_HYST_BANDED"); force = (e && *e) ? (*e != '0' ? 1 : 0) : -1; }
+  const int force = g.hyst_force;  // per context (revo_host.hip: build_geom reads REVO_HYST_BANDED when the context is created)
   const bool fits_single = ec_bytes + 4096 <= REVO_HYST_LDS_MAX;
   const bool banded = force >= 0 ? force == 1 : !fits_single;
   const int only_flagged = banded && g.total_bands > 0 ? 1 : 0;

@@ -1125,13 +1125,16 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
 
 // The resident gate: one wave that waits (bounded, sleeping) until the census counter of the tracker launches has
 // reached `want`, i.e. until every workgroup of the previous tracker grid of this device has started.
-__global__ void __launch_bounds__(64) k_track_gate(const unsigned* __restrict__ resident, unsigned want) {
+// resident[1] counts the gates that gave up (bounded wait, ~2 s): the next grid then starts anyway and the in-kernel bounded
+// spin + flag 8 are what is left -- the counter makes that fall-through observable (revo_debug_gate_timeouts_).
+__global__ void __launch_bounds__(64) k_track_gate(unsigned* __restrict__ resident, unsigned want) {
   if (threadIdx.x != 0) return;
   for (unsigned spins = 0; spins < 4u * SPIN_LIMIT; ++spins) {
     const unsigned have = __hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int)(have - want) >= 0) return;
     __builtin_amdgcn_s_sleep(8);
   }
+  __hip_atomic_fetch_add(resident + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // A.ldlt().solve(b) alone (optimizer.cpp:258-262), for the parity tests of the solver
@@ -1184,7 +1187,7 @@ static unsigned next_epoch_base(unsigned* epoch_io, unsigned long long* d_mail, 
   return base;
 }
 
-void launch_track_gate(const unsigned* d_resident, unsigned want, hipStream_t s) {
+void launch_track_gate(unsigned* d_resident, unsigned want, hipStream_t s) {
   hipLaunchKernelGGL(k_track_gate, dim3(1), dim3(64), 0, s, d_resident, want);
 }
 

@@ -232,3 +232,32 @@ def rot_angle(Ra, Rb):
 def pose_error(R_est, T_est, T_gt):
     """(rotation error rad, translation error m) of (R,T) vs a 4x4 ground truth."""
     return rot_angle(R_est, T_gt[:3, :3]), float(np.linalg.norm(np.asarray(T_est, np.float64) - T_gt[:3, 3]))
+
+
+def _pair_job(args):
+    seed, w, h, fx, fy, cx, cy = args
+
+    class _K:  # the camera fields make_pair reads
+        pass
+    k = _K()
+    k.width, k.height, k.fx, k.fy, k.cx, k.cy = w, h, fx, fy, cx, cy
+    return make_pair(seed, k)
+
+
+def make_pairs(seeds, settings, workers=None):
+    """make_pair for many seeds on several host cores (rendering a 640x480 pair takes ~0.3 s).  The workers are SPAWNED,
+    not forked: the calling process may hold an initialised HIP runtime (GPU tests), and this module imports numpy only."""
+    import multiprocessing as mp
+    import os
+    seeds = list(seeds)
+    jobs = [(sd, settings.width, settings.height, settings.fx, settings.fy, settings.cx, settings.cy) for sd in seeds]
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+        workers = max(1, min(16, workers, len(jobs)))
+    if workers <= 1:
+        return [_pair_job(j) for j in jobs]
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return pool.map(_pair_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))

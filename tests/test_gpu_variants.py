@@ -1,0 +1,118 @@
+"""GPU parity of the code paths that are NOT the default at the test sizes (VERDICT r03 "what's weak" 2-3): they used to be
+checked by hand-run tools only.
+
+* the banded hysteresis (k_hyst_band / k_hyst_seam / k_hyst_out) forced at sizes where one workgroup per level would do,
+  with three band sizes -- bit-exact vs the oracle on the Canny edge cases;
+* a 128-pair slice of tests/tools/soak_gpu_tracker.py at the bench geometry: the DISTRIBUTION behind the stated tracker
+  tolerance (1e-4 rad / 1e-4 m holds for >= 98 % of the pairs, all pairs within 5e-3).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from revo_amd import synth  # noqa: E402
+from revo_amd.settings import ImgPyramidSettings, OptimizerSettings, TrackerSettings  # noqa: E402
+
+from test_gpu_parity import _edge_cases, compare_pyramid  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def api():
+    from revo_amd import api as A
+    return A
+
+
+@pytest.fixture(scope="module")
+def ro():
+    from oracle import ro as R
+    return R
+
+
+@pytest.mark.parametrize("size", [(320, 240), (640, 480)])
+@pytest.mark.parametrize("band_words", [600, 1200, 2400])
+def test_banded_hysteresis_forced_bit_exact(api, ro, monkeypatch, size, band_words):
+    """REVO_HYST_BANDED=1 makes every level take the banded path (several workgroups per level and frame + the exact seam
+    pass), REVO_HYST_BAND_WORDS sets the band height: 2 to 16 bands per level here.  The library reads both when the
+    context is created.  Everything downstream of the edges (histogram, fill-in, lists, DT) rides along."""
+    w, h = size
+    monkeypatch.setenv("REVO_HYST_BANDED", "1")
+    monkeypatch.setenv("REVO_HYST_BAND_WORDS", str(band_words))
+    s = ImgPyramidSettings.scaled(w, h, 3, hist_patch=(20, 10, 5, 0, 0, 0) if w == 640 else (10, 5, 0, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    for name, bgr, depth in _edge_cases(s):
+        gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+        op = ro.Pyramid(s, bgr, depth)
+        compare_pyramid("band%d_%dx%d_%s" % (band_words, w, h, name), gp, op, s, False)
+
+
+def test_banded_and_single_hysteresis_agree_on_a_batch(api, monkeypatch):
+    """The same 8 frames through a batch build with the banded path forced and with the single workgroup forced: identical
+    edge planes, histograms and tracker-ordered lists (the two paths never run in the same context otherwise)."""
+    import torch
+    s = ImgPyramidSettings.scaled(640, 480, 4, hist_patch=(20, 10, 5, 0, 0, 0))
+    pairs = [synth.make_pair(900 + i, s) for i in range(4)]
+    bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).cuda()
+    dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).cuda()
+    recs = {}
+    for force in ("1", "0"):
+        monkeypatch.setenv("REVO_HYST_BANDED", force)
+        cam = api.CameraPyr(s)
+        api.TrackerNew(TrackerSettings(), s, cam)
+        bt = api.BatchTracker(cam, 4)
+        res = torch.zeros(4 * 96, dtype=torch.uint8, device="cuda")
+        bt.track(bgr.data_ptr(), dep.data_ptr(), res.data_ptr())
+        bt.sync()
+        planes = []
+        for f in range(8):
+            v = bt.frame(f, s)
+            for lvl in range(4):
+                planes.append(v.returnEdges(lvl).copy())
+                planes.append(v.edges3DTiled(lvl).copy())
+        recs[force] = (res.cpu().numpy().tobytes(), planes)
+    assert recs["1"][0] == recs["0"][0], "tracker records differ between the two hysteresis paths"
+    for a, b in zip(recs["1"][1], recs["0"][1]):
+        assert np.array_equal(a, b)
+
+
+def test_tracker_tolerance_distribution_128_pairs(api, ro, capsys):
+    """The soak tool's statement as a test: 128 seeded 640x480 / 4-level pairs through bench-sized batches (32 pairs, the
+    bench's cluster shape) against the oracle, pair by pair.  Two faithful implementations of this LM may stop at different
+    points inside its convergence slack (borderline `error < lastErr` / `> 0.999` decisions on sums of ~1e4 float terms,
+    optimizer.cpp:273-278), so the tolerance is a distribution: >= 97 % of the pairs within 1e-5 rad / 1e-5 m, <= 2 % outside
+    1e-4, none above 5e-3, no flag.  The share of pairs with identical per-level evaluation counts is printed."""
+    import torch
+    n, seed0 = 128, 1000
+    s = ImgPyramidSettings.scaled(640, 480, 4, hist_patch=(20, 10, 5, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    bt = api.BatchTracker(cam, 32)
+    ot = ro.Tracker(s, OptimizerSettings(), TrackerSettings())
+    drot, dtr, same_evals, flagged = [], [], 0, 0
+    for b0 in range(0, n, 32):
+        pairs = [synth.make_pair(seed0 + b0 + i, s) for i in range(32)]
+        bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).cuda()
+        dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).cuda()
+        d_res = torch.zeros(32 * 96, dtype=torch.uint8, device="cuda")
+        bt.track(bgr.data_ptr(), dep.data_ptr(), d_res.data_ptr())
+        bt.sync()
+        res = api.results_from_buffer(d_res.cpu().numpy().tobytes(), 32)
+        for i, p in enumerate(pairs):
+            o_ref, o_cur = ro.Pyramid(s, *p["ref"]), ro.Pyramid(s, *p["curr"])
+            o_ref.makeKeyframe()
+            r_o = ot.trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
+            drot.append(synth.rot_angle(res[i]["R"], r_o["R"]))
+            dtr.append(float(np.linalg.norm(res[i]["T"] - r_o["T"])))
+            same_evals += list(res[i]["evals"][:4]) == list(r_o["evals"][:4])
+            flagged += bool(res[i]["flags"] & (2 | 4 | 8))
+    drot, dtr = np.array(drot), np.array(dtr)
+    in5 = int(((drot < 1e-5) & (dtr < 1e-5)).sum())
+    out4 = int(((drot >= 1e-4) | (dtr >= 1e-4)).sum())
+    with capsys.disabled():
+        print("\n[soak slice] %d pairs: within 1e-5: %d, outside 1e-4: %d, max %.2e rad %.2e m, median %.2e rad %.2e m, "
+              "identical evaluation counts: %d (%.0f %%)"
+              % (n, in5, out4, drot.max(), dtr.max(), np.median(drot), np.median(dtr), same_evals, 100.0 * same_evals / n))
+    assert flagged == 0
+    assert in5 >= 0.97 * n, "only %d of %d pairs within 1e-5" % (in5, n)
+    assert out4 <= 0.02 * n, "%d of %d pairs outside 1e-4" % (out4, n)
+    assert drot.max() < 5e-3 and dtr.max() < 5e-3
