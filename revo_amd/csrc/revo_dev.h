@@ -37,7 +37,6 @@ struct PyrGeom {
   int frame0;  // first frame of this launch (blockIdx.z counts from it): lets a batch be split across streams
   int n_levels;
   int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
-  int nms_px;          // pixels per thread of the Canny NMS kernel the block counts below were made for (8 or 4)
   int total_bands, any_banded;  // hysteresis bands of all levels; 1 if some level has more than one
   int hyst_force;      // -1: banded hysteresis where a level does not fit one workgroup (default); 1 / 0: always / never (REVO_HYST_BANDED)
   int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
@@ -110,7 +109,7 @@ struct EvalOut {
 };
 
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
-#define NMS_ROWS 6                  // output rows per k_canny_nms thread (8 pixels wide)
+#define NMS_ROWS 6                  // output rows per k_canny_nms4 thread (4 pixels wide)
 #define EDT_ROW_PX 1280             // pixels per k_edt_rows workgroup (whole rows)
 #define REVO_HYST_LDS_MAX 158720    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
 #ifndef TRACK_THREADS

@@ -186,7 +186,6 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   }
   g->n_levels = L;
   { const char* e = getenv("REVO_HYST_BANDED"); g->hyst_force = (e && *e) ? (*e != '0' ? 1 : 0) : -1; }
-  g->nms_px = env_int("REVO_NMS_PX", 4, 4, 8) == 8 ? 8 : 4;
   g->depth_min = s.depth_min; g->depth_max = s.depth_max;
   // cv::Canny with L2gradient: low/high swapped if needed, squared (imgpyramidrgbd.cpp:184)
   double lo = s.canny_threshold1, hi = s.canny_threshold2;
@@ -216,7 +215,7 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     g->fill_thr[l] = (double)(v.patch * v.patch) * 0.05;  // imgpyramidrgbd.cpp:133
     v.chunk_rows = 32; v.nchunk = (v.h + 31) / 32;
     v.wpr = (v.w + 31) / 32;
-    v.nms_block_base = tile; tile += ((32 / g->nms_px) * v.wpr * ((v.h + NMS_ROWS - 1) / NMS_ROWS) + 255) / 256;
+    v.nms_block_base = tile; tile += (8 * v.wpr * ((v.h + NMS_ROWS - 1) / NMS_ROWS) + 255) / 256;
     // the level's edge bitmap must fit the LDS of one workgroup (k_hyst)
     if (((size_t)(v.h + 2) * v.wpr + 2) * 4 > REVO_HYST_LDS_MAX) { *why = "image too large: (height + 2) x ceil(width/32) bitmap words must fit 155 KB of LDS"; return -1; }
     v.pix_base = pix; pix += v.npix;

@@ -179,12 +179,12 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
 // a5 (first half): cv::Canny's Sobel 3x3 (BORDER_REPLICATE) + L2 magnitude +
 // non-maximum suppression (imgpyramidrgbd.cpp:184).
 //
-// One thread = 8 pixels x NMS_R rows, everything in registers: no LDS, no barrier, no
-// cross-lane traffic except the final 4-lane OR that assembles a 32-pixel bitmap word.
-// Per gray row the thread loads 4 aligned words (its 8 pixels + 4 on either side; the
+// One thread = 4 pixels x NMS_R rows, everything in registers: no LDS, no barrier, no
+// cross-lane traffic except the final 8-lane OR that assembles a 32-pixel bitmap word.
+// Per gray row the thread loads 3 aligned words (its 4 pixels + 4 on either side; the
 // neighbours' words come out of L1) and forms, with packed 16-bit arithmetic on column
 // PAIRS, the horizontal difference d = g[c+1] - g[c-1] and smooth s = g[c-1] + 2 g[c] + g[c+1]
-// of 10 columns (x-1 .. x+8).  Three consecutive rows give dx = d0 + 2 d1 + d2 and
+// of 6 columns (x-1 .. x+4).  Three consecutive rows give dx = d0 + 2 d1 + d2 and
 // dy = s2 - s0 (exact in int16: |.| <= 1020); one v_perm packs (dx,dy) of a column and one
 // v_dot2 squares it: |grad|^2 = dx^2 + dy^2.  The magnitude rows stream through registers, so NMS
 // sees its 3x3 neighbourhood without ever storing a magnitude.  (Round 1 staged gray, magnitudes
@@ -199,58 +199,6 @@ __device__ __forceinline__ s2v as_s2(uint32_t v) { return __builtin_bit_cast(s2v
 __device__ __forceinline__ uint32_t as_u32(s2v v) { return __builtin_bit_cast(uint32_t, v); }
 // two bytes of the 8-byte value {hi:lo} zero-extended into the halves of a dword (v_perm_b32, selector 0x0c = 0x00)
 #define PAIR(hi, lo, sel) as_s2(__builtin_amdgcn_perm((hi), (lo), (sel)))
-
-struct HRow { s2v d[5], s[5]; };  // column pairs (-1,0) (1,2) (3,4) (5,6) (7,8) relative to the thread's first pixel
-
-// prev = g[-4..-1], m0 = g[0..3], m1 = g[4..7], next = g[8..11]
-__device__ __forceinline__ HRow hrow(uint32_t prev, uint32_t m0, uint32_t m1, uint32_t next) {
-  // even pairs E_k = (g[2k-2], g[2k-1]), odd pairs O_k = (g[2k-1], g[2k])
-  const s2v E0 = PAIR(0u, prev, 0x0c030c02u), E1 = PAIR(0u, m0, 0x0c010c00u), E2 = PAIR(0u, m0, 0x0c030c02u);
-  const s2v E3 = PAIR(0u, m1, 0x0c010c00u), E4 = PAIR(0u, m1, 0x0c030c02u), E5 = PAIR(0u, next, 0x0c010c00u);
-  const s2v O0 = PAIR(m0, prev, 0x0c040c03u), O1 = PAIR(0u, m0, 0x0c020c01u), O2 = PAIR(m1, m0, 0x0c040c03u);
-  const s2v O3 = PAIR(0u, m1, 0x0c020c01u), O4 = PAIR(next, m1, 0x0c040c03u);
-  HRow r;
-  r.d[0] = E1 - E0; r.d[1] = E2 - E1; r.d[2] = E3 - E2; r.d[3] = E4 - E3; r.d[4] = E5 - E4;
-  r.s[0] = (E0 + E1) + (O0 + O0); r.s[1] = (E1 + E2) + (O1 + O1); r.s[2] = (E2 + E3) + (O2 + O2);
-  r.s[3] = (E3 + E4) + (O3 + O3); r.s[4] = (E4 + E5) + (O4 + O4);
-  return r;
-}
-
-// A row of magnitudes / gradients is a struct of NAMED scalars, every access spelled with a literal field: the
-// optimiser then sees plain values from the first pass on.  Both an array (indexed inside unrolled loops) and a
-// vector type were pessimised by "select(c, X[i], X[j]) -> X[select(c, i, j)]": the array ended up in scratch
-// memory behind a selected pointer (420 MB of HBM traffic per launch), the vector in 16-deep compare/select chains.
-struct MRow { int v0, v1, v2, v3, v4, v5, v6, v7, v8, v9; };          // |grad|^2 of columns -1..8
-struct DRow { uint32_t v0, v1, v2, v3, v4, v5, v6, v7; };            // (dx | dy << 16) of columns 0..7
-
-// Sobel of the row between a (above) and c (below), b the row itself; cm[]: column masks (0 outside the image)
-__device__ __forceinline__ void mag_row(const HRow& a, const HRow& b, const HRow& c, const uint32_t* cm, bool valid, MRow& m,
-                                        DRow& dxy) {
-  uint32_t lo[5], hi[5];  // column 2k-1: low halves, column 2k: high halves
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const s2v dx = (a.d[k] + c.d[k]) + (b.d[k] + b.d[k]);
-    const s2v dy = c.s[k] - a.s[k];
-    lo[k] = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x05040100u);
-    hi[k] = __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x07060302u);
-  }
-  // |grad|^2 outside the image is 0 (cv::Canny pads its magnitude buffer with zeros); columns 0..3 of an
-  // active thread are always inside; `valid` is the row's mask (a row above / below the image, an idle thread)
-  const uint32_t rv = valid ? ~0u : 0u;
-#define MAG2(x) __builtin_amdgcn_sdot2(as_s2(x), as_s2(x), 0, false)
-  m.v0 = MAG2(lo[0]) & (int)(cm[0] & rv);
-  m.v1 = MAG2(hi[0]) & (int)rv;
-  m.v2 = MAG2(lo[1]) & (int)rv;
-  m.v3 = MAG2(hi[1]) & (int)rv;
-  m.v4 = MAG2(lo[2]) & (int)rv;
-  m.v5 = MAG2(hi[2]) & (int)(cm[1] & rv);
-  m.v6 = MAG2(lo[3]) & (int)(cm[2] & rv);
-  m.v7 = MAG2(hi[3]) & (int)(cm[3] & rv);
-  m.v8 = MAG2(lo[4]) & (int)(cm[4] & rv);
-  m.v9 = MAG2(hi[4]) & (int)(cm[5] & rv);
-#undef MAG2
-  dxy.v0 = hi[0]; dxy.v1 = lo[1]; dxy.v2 = hi[1]; dxy.v3 = lo[2]; dxy.v4 = hi[2]; dxy.v5 = lo[3]; dxy.v6 = hi[3]; dxy.v7 = lo[4];
-}
 
 // NMS of one pixel (cv::Canny): its 3x3 neighbourhood of |grad|^2 by value, its own gradient; sets bit k of cand / strong
 __device__ __forceinline__ void nms_px(int k, int aL, int aM, int aR, int bL, int m, int bR, int cL, int cM, int cR, uint32_t dxy,
@@ -275,119 +223,9 @@ __device__ __forceinline__ void nms_px(int k, int aL, int aM, int aR, int bL, in
   cb |= c ? (1u << k) : 0u;
   sb |= (c & (m > high)) ? (1u << k) : 0u;
 }
-// NMS of one row: 8 candidate bits and 8 strong bits.  A, B, C: |grad|^2 of the rows above, at and below; d: the row's gradients
-__device__ __forceinline__ void nms_row(const MRow& A, const MRow& B, const MRow& C, const DRow& d, int low, int high,
-                                        uint32_t* cand, uint32_t* strong) {
-  uint32_t cb = 0, sb = 0;
-  nms_px(0, A.v0, A.v1, A.v2, B.v0, B.v1, B.v2, C.v0, C.v1, C.v2, d.v0, low, high, cb, sb);
-  nms_px(1, A.v1, A.v2, A.v3, B.v1, B.v2, B.v3, C.v1, C.v2, C.v3, d.v1, low, high, cb, sb);
-  nms_px(2, A.v2, A.v3, A.v4, B.v2, B.v3, B.v4, C.v2, C.v3, C.v4, d.v2, low, high, cb, sb);
-  nms_px(3, A.v3, A.v4, A.v5, B.v3, B.v4, B.v5, C.v3, C.v4, C.v5, d.v3, low, high, cb, sb);
-  nms_px(4, A.v4, A.v5, A.v6, B.v4, B.v5, B.v6, C.v4, C.v5, C.v6, d.v4, low, high, cb, sb);
-  nms_px(5, A.v5, A.v6, A.v7, B.v5, B.v6, B.v7, C.v5, C.v6, C.v7, d.v5, low, high, cb, sb);
-  nms_px(6, A.v6, A.v7, A.v8, B.v6, B.v7, B.v8, C.v6, C.v7, C.v8, d.v6, low, high, cb, sb);
-  nms_px(7, A.v7, A.v8, A.v9, B.v7, B.v8, B.v9, C.v7, C.v8, C.v9, d.v7, low, high, cb, sb);
-  *cand = cb;
-  *strong = sb;
-}
-
 #define NMS_R 6
-#ifdef NMS_WAVES_PER_EU
-#define NMS_OCC __attribute__((amdgpu_waves_per_eu(NMS_WAVES_PER_EU, NMS_WAVES_PER_EU)))
-#else
-#define NMS_OCC
-#endif
-__global__ void __launch_bounds__(256) NMS_OCC k_canny_nms(PyrGeom g, FramePlanes pl) {
-  const int f = g.frame0 + blockIdx.z;
-  if (blockIdx.x == 0 && threadIdx.x < REVO_L) {  // per-frame words the banded hysteresis accumulates into / raises
-    pl.need_full[f * REVO_L + threadIdx.x] = 0;
-    pl.hist_nz[f * REVO_L + threadIdx.x] = 0;
-  }
-  const int l = level_of(g, blockIdx.x, &LevelGeom::nms_block_base);
-  const LevelGeom& lv = g.lv[l];
-  const int w = lv.w, h = lv.h;
-  const int rt = 4 * lv.wpr;  // threads per row: a quad of threads makes one 32-pixel bitmap word
-  const int t = (blockIdx.x - lv.nms_block_base) * 256 + threadIdx.x;
-  const int yb = t / rt, xg = t - yb * rt;
-  const int y0 = yb * NMS_R;
-  if (y0 >= h) return;  // whole quads leave together (rt is a multiple of 4)
-  const int x = xg * 8;
-  const bool active = x < w;
-  const uint8_t* gray = pl.gray[l] + (size_t)f * lv.npix;
-  // word offsets inside a row (clamped, so every load is inside the row) and what to replicate at the border
-  const bool has_prev = x > 0, has_m1 = x + 4 < w, has_next = x + 8 < w;
-  const int xo = active ? x : 0;
-  const int o_prev = (active && has_prev) ? xo - 4 : xo, o_m1 = (active && has_m1) ? xo + 4 : xo, o_next = (active && has_next) ? xo + 8 : xo;
-  uint32_t cm[6];  // column masks of columns -1, 4, 5, 6, 7, 8
-  cm[0] = (active && has_prev) ? ~0u : 0u;
-#pragma unroll
-  for (int k = 1; k < 6; ++k) cm[k] = (active && x + 3 + k < w) ? ~0u : 0u;
-  // A row arrives as four raw words (columns -4..11); the words of the row a step needs are requested one step ahead,
-  // so a wave waits for memory once, not once per row (the steps are long basic blocks the scheduler does not move
-  // loads across: at one or two waves per SIMD next to a tracker every wait was a full round trip).
-  struct Raw { uint32_t prev, m0, m1, next; };
-  auto load_raw = [&](int r) -> Raw {
-    const int rr = clampi(r, 0, h - 1);  // BORDER_REPLICATE
-    const uint8_t* row = gray + (size_t)rr * w;
-    Raw q;
-    q.m0 = *reinterpret_cast<const uint32_t*>(row + xo);
-    q.prev = *reinterpret_cast<const uint32_t*>(row + o_prev);
-    q.m1 = *reinterpret_cast<const uint32_t*>(row + o_m1);
-    q.next = *reinterpret_cast<const uint32_t*>(row + o_next);
-    return q;
-  };
-  auto make_hrow = [&](Raw q) -> HRow {
-    if (!has_prev) q.prev = (q.m0 & 0xffu) * 0x01010101u;
-    if (!has_m1) q.m1 = (q.m0 >> 24) * 0x01010101u;
-    if (!has_next) q.next = (q.m1 >> 24) * 0x01010101u;
-    return hrow(q.prev, q.m0, q.m1, q.next);
-  };
-  // Three gray rows (H*) and three magnitude rows (M*, D*) in flight, as separately named values picked with
-  // compile-time indices: nothing moves, nothing is indexed dynamically.
-  HRow H0, H1, H2;
-  MRow M0, M1, M2;
-  DRow D0, D1, D2;
-  {
-    const Raw r0 = load_raw(y0 - 2), r1 = load_raw(y0 - 1), r2 = load_raw(y0), r3 = load_raw(y0 + 1);
-    H0 = make_hrow(r0); H1 = make_hrow(r1); H2 = make_hrow(r2);
-    mag_row(H0, H1, H2, cm, active && y0 - 1 >= 0, M0, D0);                // magnitude row y0 - 1
-    H0 = make_hrow(r3);
-  }
-  Raw ahead = load_raw(y0 + 2);
-  mag_row(H1, H2, H0, cm, active, M1, D1);                                 // magnitude row y0
-  uint2* out = pl.cs[l] + ((size_t)f * h + y0) * lv.wpr + (xg >> 2);
-  const int sh = 8 * (threadIdx.x & 3);
-  auto emit = [&](int i, uint32_t cb, uint32_t sb) {
-    // a quad's four bytes -> one word (DPP quad_perm: no LDS)
-    uint32_t cw = cb << sh, sw = sb << sh;
-    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0xB1, 0xf, 0xf, true);
-    cw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
-    sw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0x4E, 0xf, 0xf, true);
-    if ((threadIdx.x & 3) == 0 && y0 + i < h) out[(size_t)i * lv.wpr] = make_uint2(cw, sw);
-  };
-  // step i: gray rows y0+i, y0+i+1 sit in (Ha, Hb); row y0+i+2 replaces the oldest (Hc); magnitude rows y0+i-1, y0+i in
-  // (Ma, Mb), row y0+i+1 goes to Mc
-#define NMS_STEP(i, Ha, Hb, Hc, Ma, Mb, Mc, Db, Dc)                                   \
-  {                                                                                   \
-    Hc = make_hrow(ahead);                                                            \
-    if ((i) < NMS_R - 1) ahead = load_raw(y0 + (i) + 3);                              \
-    mag_row(Ha, Hb, Hc, cm, active && y0 + (i) + 1 < h, Mc, Dc);                      \
-    uint32_t cb, sb;                                                                  \
-    nms_row(Ma, Mb, Mc, Db, g.canny_low, g.canny_high, &cb, &sb);                     \
-    emit((i), cb, sb);                                                                \
-  }
-  NMS_STEP(0, H2, H0, H1, M0, M1, M2, D1, D2)
-  NMS_STEP(1, H0, H1, H2, M1, M2, M0, D2, D0)
-  NMS_STEP(2, H1, H2, H0, M2, M0, M1, D0, D1)
-  NMS_STEP(3, H2, H0, H1, M0, M1, M2, D1, D2)
-  NMS_STEP(4, H0, H1, H2, M1, M2, M0, D2, D0)
-  NMS_STEP(5, H1, H2, H0, M2, M0, M1, D0, D1)
-#undef NMS_STEP
-  static_assert(NMS_R == 6, "six steps above");
-}
 
-// The same kernel with FOUR pixels per thread (columns -1 .. 4 in flight instead of -1 .. 8): ~60 registers instead of
+// FOUR pixels per thread (columns -1 .. 4 in flight; an 8-pixel form of the same kernel, columns -1 .. 8, existed until round 4): ~60 registers instead of
 // 104.  It runs ~14 % more instructions (the halo columns are shared by fewer outputs), but the build shares every CU
 // with two resident tracker workgroups (2 x 168 VGPRs per SIMD lane slot): 176 registers are left, i.e. ONE wave per SIMD
 // of the 8-pixel kernel (42 us alone, 82-89 us in the pipelined step) against two or three of this one.
@@ -2183,10 +2021,8 @@ void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipS
                      p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max);
 }
 
-// nms_px = pixels per thread the geometry's block counts were made for (revo_host.hip: build_geom): 8 or 4
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  if (g.nms_px == 4) hipLaunchKernelGGL(k_canny_nms4, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
-  else hipLaunchKernelGGL(k_canny_nms, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
+  hipLaunchKernelGGL(k_canny_nms4, dim3(g.total_nms_blocks, 1, B), dim3(256), 0, s, g, p);
 }
 
 // hysteresis + edge planes + tile histograms: one workgroup per (level, frame)
