@@ -157,8 +157,12 @@ def dry_run_cpu(a, world, rank, json_fd):
     for _ in range(a.steps):
         got = parallel.gather_records(local, world, out=out)
     dist.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, world)
+    mine_s = time.perf_counter() - t0
+    per_rank = parallel.gather_floats(mine_s, world)
+    elapsed = parallel.max_over_ranks(mine_s, world)
     seen, wsz = parallel.ranks_seen(world)
+    if len(set(seen)) != world or wsz != world:
+        raise SystemExit("bench --dry-run-cpu: the process group saw ranks %s (size %d) but WORLD_SIZE is %d" % (seen, wsz, world))
     g = got.numpy().view(np.float32).reshape(world * a.pairs, -1)
     if not (np.array_equal(g[:, 0], np.arange(world * a.pairs, dtype=np.float32))
             and np.array_equal(g[:, 9], np.repeat(np.arange(world, dtype=np.float32), a.pairs))):
@@ -166,6 +170,7 @@ def dry_run_cpu(a, world, rank, json_fd):
     if rank == 0:
         line = {"metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference", "value": None, "unit": "frames/s",
                 "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
+                "ms_per_step_per_rank": [x / max(1, a.steps) * 1e3 for x in per_rank],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none (stubbed step)",
                 "config": {"workload": "orchestration dry run on CPU (gloo): no kernels", "pairs_per_gpu": a.pairs,
                            "global_pairs": world * a.pairs},
@@ -205,6 +210,9 @@ def main():
     ap.add_argument("--track-streams", type=int, default=2,
                     help="streams the tracker launches alternate over (the library keeps REVO_TRACK_DEPTH grids in flight, "
                          "default 2; more streams than that buy nothing)")
+    ap.add_argument("--edt-streams", type=int, default=0,
+                    help="streams that run the keyframes' distance transforms the build leaves to its first consumer "
+                         "(revo_batch_prepare); 0 = on the tracker's stream, in front of the grid")
     ap.add_argument("--build-streams", type=int, default=1, help="experiment: builds of consecutive steps alternate over this many streams")
     ap.add_argument("--input-batches", type=int, default=3,
                     help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
@@ -302,7 +310,8 @@ def main():
             drv.run(stream_frames)  # IO thread builds pyramids into the queue, this thread tracks (system.cpp:96)
             runs.append(time.perf_counter() - t0)
         rpe = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
-        seq_gpu = {"runs": runs, "keyframes": drv.nKeyFrames, "rpe": rpe,
+        seq_gpu = {"runs": runs, "keyframes": drv.nKeyFrames, "rpe": rpe, "poses": [np.array(p[1]) for p in drv.poses],
+                   "gt": [f[3] for f in seq],
                    "ate": synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])}
         del drv
 
@@ -331,7 +340,8 @@ def main():
     # tracker of step k (192 latency-bound workgroups).  Trackers serialise on one stream,
     # builds on the other; events hand each batch back and forth.
     nbuf = 1 if a.no_overlap else max(2, a.buffers)
-    bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf)]
+    nbuf_alloc = max(2, nbuf)  # (the two-batch side measurement below needs two)
+    bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf_alloc)]
     bt = bts[0]
     d_bgrs = [torch.from_numpy(b).to(dev) for b in bgrs]
     d_deps = [torch.from_numpy(d).to(dev) for d in deps]
@@ -341,21 +351,20 @@ def main():
     d_res_all = torch.zeros(max(1, n_slots) * a.pairs * 96, dtype=torch.uint8, device=dev)
     d_ress = [d_res_all[i * a.pairs * 96:(i + 1) * a.pairs * 96] for i in range(max(1, n_slots))]
     d_res = d_ress[0]
+    d_res_side = torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev)  # side measurements write here
     s_track = torch.cuda.Stream(device=dev)
     # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
     # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
     n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
     s_tracks = [s_track] + [torch.cuda.Stream(device=dev) for _ in range(n_tr - 1)]
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
-    s_build = torch.cuda.Stream(device=dev) if nbuf >= 2 else s_track
+    s_build = torch.cuda.Stream(device=dev)
     # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
     s_builds = [s_build] + [torch.cuda.Stream(device=dev) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
+    s_edts = [torch.cuda.Stream(device=dev) for _ in range(max(0, a.edt_streams) if nbuf >= 2 else 0)]
     torch.cuda.set_stream(s_track)
     stream = s_track.cuda_stream
     assert stream != 0 and s_build.cuda_stream != 0
-    ev_built = [torch.cuda.Event() for _ in range(nbuf)]
-    ev_tracked = [torch.cuda.Event() for _ in range(nbuf)]
-    counter = [0]
     # the timing events cost ~1.5 % of the step when every launch carries a pair (two marker packets in front of / behind
     # each tracker on its stream): every 4th launch of the timed region is timed (every launch when there are few)
     TIME_EVERY = int(os.environ.get('REVO_BENCH_TIME_EVERY', '4' if a.steps >= 16 else '1'))
@@ -363,37 +372,57 @@ def main():
     gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
     d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if use_group else None
 
-    def step():
-        k = counter[0] % nbuf
-        d_out = d_ress[counter[0] % len(d_ress)]
-        j_in = counter[0] % nin                      # the input batches rotate: step t reads input t mod nin
-        s_tr = s_tracks[counter[0] % len(s_tracks)]
-        s_bld = s_builds[counter[0] % len(s_builds)]
-        counter[0] += 1
-        if nbuf >= 2:
-            s_bld.wait_event(ev_tracked[k])          # batch k free again (its previous tracker is done)
-            bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_bld.cuda_stream, borrow_depth=True)
-            ev_built[k].record(s_bld)
-            s_tr.wait_event(ev_built[k])
-            if timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
-                e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                bts[k].prepare(stream=s_tr.cuda_stream)  # the keyframes' EDT the build left to this stream: not k_track
-                e_a.record(s_tr)
+    def make_step(nb, tracks, builds, edts, outs, main):
+        """One pipeline shape: `nb` batches in rotation, tracker grids alternating over `tracks`, builds over `builds`,
+        the deferred keyframe EDTs on `edts` (empty: on the tracker's stream).  main: the timed headline loop (records of
+        every step kept, k_track timed live, the collective in the loop)."""
+        ev_built = [torch.cuda.Event() for _ in range(nb)]
+        ev_edt = [torch.cuda.Event() for _ in range(nb)]
+        ev_tracked = [torch.cuda.Event() for _ in range(nb)]
+        counter = [0]
+
+        def step():
+            t = counter[0]
+            k = t % nb
+            d_out = outs[t % len(outs)]
+            j_in = t % nin                      # the input batches rotate: step t reads input t mod nin
+            s_tr = tracks[t % len(tracks)]
+            counter[0] += 1
+            if nb >= 2:
+                s_bld = builds[t % len(builds)]
+                s_bld.wait_event(ev_tracked[k])          # batch k free again (its previous tracker is done)
+                bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_bld.cuda_stream, borrow_depth=True)
+                ev_built[k].record(s_bld)
+                if edts:  # the keyframes' EDT on its own stream: off the build stream's chain AND off the tracker's
+                    s_e = edts[t % len(edts)]
+                    s_e.wait_event(ev_built[k])
+                    bts[k].prepare(stream=s_e.cuda_stream)
+                    ev_edt[k].record(s_e)
+                    s_tr.wait_event(ev_edt[k])
+                else:
+                    s_tr.wait_event(ev_built[k])
+                if main and timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
+                    e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    bts[k].prepare(stream=s_tr.cuda_stream)  # the keyframes' EDT the build left to this stream: not k_track
+                    e_a.record(s_tr)
+                    bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
+                    e_b.record(s_tr)
+                    track_events.append((e_a, e_b))
+                else:
+                    bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
+            else:  # one batch, one stream: nothing overlaps anything
+                bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_tr.cuda_stream, borrow_depth=True)
                 bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-                e_b.record(s_tr)
-                track_events.append((e_a, e_b))
-            else:
-                bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-        else:
-            bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=stream, borrow_depth=True)
-            bts[k].track_only(d_out.data_ptr(), stream=stream)
-        ev_tracked[k].record(s_tr)
-        if use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
-            # nothing on the device waits for it (the host reads the gathered records after the run), so it is off the
-            # tracker stream's chain; it is inside the timed region all the same (synchronize + barrier below)
-            s_coll.wait_event(ev_tracked[k])
-            with torch.cuda.stream(s_coll):
-                gathered[0] = parallel.gather_records(d_out, world, out=d_all)
+            ev_tracked[k].record(s_tr)
+            if main and use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
+                # nothing on the device waits for it (the host reads the gathered records after the run), so it is off the
+                # tracker stream's chain; it is inside the timed region all the same (synchronize + barrier below)
+                s_coll.wait_event(ev_tracked[k])
+                with torch.cuda.stream(s_coll):
+                    gathered[0] = parallel.gather_records(d_out, world, out=d_all)
+        return step, counter
+
+    step, counter = make_step(nbuf, s_tracks, s_builds, s_edts, d_ress, True)
 
     for _ in range(a.warmup):
         step()
@@ -411,6 +440,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing[0] = False
+    ms_per_rank = [x / a.steps * 1e3 for x in parallel.gather_floats(elapsed, world, device=dev)] if use_group else [elapsed / a.steps * 1e3]
     elapsed = parallel.max_over_ranks(elapsed, world, device=dev)
     d_res = d_ress[(counter[0] - 1) % len(d_ress)]
     bt = bts[(counter[0] - 1) % nbuf]
@@ -485,6 +515,23 @@ def main():
         tk += e1.elapsed_time(e2)
     ms_build, ms_trk_stage = tb / reps, tk / reps
 
+    # ---- what "32 frame-pairs in flight" means, stated three ways: `value` keeps `nbuf` batches in rotation
+    # (declared in config.pipelining / pairs_resident); next to it the SAME step with ONE batch and nothing overlapped
+    # (build -> keyframes -> tracker on one stream) and with TWO batches (the build of step k+1 next to the tracker of step
+    # k, one tracker stream).  Same kernels, same inputs, no collective; 3 warm-up + 20 timed steps each, this rank only.
+    def side_rate(nb):
+        st, _ = make_step(nb, [s_track], [s_build], [], [d_res_side], False)
+        for _ in range(3):
+            st()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        for _ in range(20):
+            st()
+        torch.cuda.synchronize()
+        return a.pairs * 20 / (time.perf_counter() - t0s)
+    value_single = side_rate(1) if not a.no_overlap else a.pairs * a.steps / elapsed
+    value_two = side_rate(2) if not a.no_overlap else None
+
     # HBM traffic of k_track per launch from the PMC passes recorded under profiles/ (same workload;
     # counters cannot be collected inside this process)
     traffic = None
@@ -514,6 +561,8 @@ def main():
         except RuntimeError:
             copy_gbs = None
     seen, group_size = parallel.ranks_seen(world, device=dev) if use_group else ([0], 1)
+    if use_group and (len(set(seen)) != world or group_size != world):
+        raise SystemExit("bench: the process group saw ranks %s (size %d) but WORLD_SIZE is %d" % (seen, group_size, world))
     gather_us = None
     if use_group:  # the collective alone (latency-bound: 96 B x pairs per rank)
         torch.cuda.synchronize()
@@ -532,11 +581,16 @@ def main():
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
+        "ms_per_step_per_rank": ms_per_rank,  # every rank's own clock around the same timed region (a straggler GPU shows here)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        # the same step with fewer batches resident (this rank, no collective): ONE batch and nothing overlapped / TWO batches
+        "value_single_batch_in_flight": value_single * world if value_single else None,
+        "value_two_batches": value_two * world if value_two else None,
+        "value_pairs_resident": {"value": nbuf * a.pairs, "value_two_batches": 2 * a.pairs, "value_single_batch_in_flight": a.pairs},
         "config": {
             "workload": "synthetic %dx%d RGB-D, %d-level pyramid, %d independent frame-pairs in flight per GPU "
                         "(BASELINE configs[%d]); per pair: 2 pyramid builds + keyframe (EDT+table) + trackFrames"
@@ -545,7 +599,8 @@ def main():
             "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
             "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
                                                         "earlier ones; consecutive tracker grids on %d stream(s), ordered by the library's "
-                                                        "resident gate (at most %s in flight)" % (nbuf, a.pairs, len(s_tracks), os.environ.get("REVO_TRACK_DEPTH", "2"))),
+                                                        "resident gate (at most %s in flight)%s" % (nbuf, a.pairs, len(s_tracks), os.environ.get("REVO_TRACK_DEPTH", "2"),
+                                                                                                  "; the keyframes' distance transforms on %d stream(s) of their own" % len(s_edts) if s_edts else "")),
             "batches_in_rotation": nbuf, "pairs_resident": nbuf * a.pairs,
         },
         "roofline": {
@@ -602,22 +657,28 @@ def main():
             ref_res = hb.track(fr)  # the records every later job must repeat
             for j in [hb.submit(fr) for _ in range(3)]:  # warm-up: all three job slots exist before the clock starts
                 hb.wait(j)
-            jobs = deque()
             k_steps = max(8, a.steps)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k_steps):
-                jobs.append(hb.submit(fr))
-                if len(jobs) == 3:
+            reps_h = []
+            for _ in range(3):  # three repetitions, ALL reported, the median is the figure (r03: 41 vs 17 GB/s between two runs)
+                jobs = deque()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k_steps):
+                    jobs.append(hb.submit(fr))
+                    if len(jobs) == 3:
+                        last = hb.wait(jobs.popleft())
+                while jobs:
                     last = hb.wait(jobs.popleft())
-            while jobs:
-                last = hb.wait(jobs.popleft())
-            dt_h = time.perf_counter() - t0
-            if any(not (np.array_equal(x["R"], y["R"]) and np.array_equal(x["T"], y["T"])) for x, y in zip(last, ref_res)):
-                raise SystemExit("bench: pipelined host-buffer jobs disagree with the first one")
+                reps_h.append(time.perf_counter() - t0)
+                if any(not (np.array_equal(x["R"], y["R"]) and np.array_equal(x["T"], y["T"])) for x, y in zip(last, ref_res)):
+                    raise SystemExit("bench: pipelined host-buffer jobs disagree with the first one")
+            dt_h = float(np.median(reps_h))
             step_bytes = a.pairs * 2 * a.width * a.height * (3 + (2 if scale else 4))
             hostb[tag] = {"value_incl_h2d": a.pairs * k_steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / k_steps * 1e3,
-                          "h2d_bytes_per_step": step_bytes, "pcie_gbs": step_bytes * k_steps / dt_h / 1e9, "steps": k_steps}
+                          "h2d_bytes_per_step": step_bytes, "pcie_gbs": step_bytes * k_steps / dt_h / 1e9, "steps": k_steps,
+                          "statistic": "median of 3 repetitions",
+                          "value_incl_h2d_runs": [a.pairs * k_steps / t for t in reps_h],
+                          "pcie_gbs_runs": [step_bytes * k_steps / t / 1e9 for t in reps_h]}
             del hb
         hostb["note"] = ("revo_track_pairs_submit/_wait from page-locked host frames, 3 jobs in flight: the H2D of job k+1 overlaps the "
                          "kernels of job k; u16 = raw depth as on disk (conversion fused into the build), f32 = metres")
@@ -632,15 +693,20 @@ def main():
         ate_seq = seq_gpu["ate"]
         rpe_t, rpe_r = seq_gpu["rpe"]
         cpu_seq = cpu_seq_2core = cpu_trk_only = None
+        traj_rmse = ate_gpu_n = ate_cpu_n = None
+        nseq = 0
         seq_pinned, seq_passes = None, 0
         if a.cpu_baseline != "off":  # the same stream through the oracle's REVO::start restatement
             from oracle import ro
             nseq = min(n, 40)
             ovo = ro.VO(s)
             t0 = time.perf_counter()
-            for fr in stream_frames[:nseq]:
-                ovo.push(*fr)
+            o_poses = [ovo.push(*fr)[0] for fr in stream_frames[:nseq]]
             cpu_seq = nseq / (time.perf_counter() - t0)  # everything on one core
+            # "ATE vs reference" (the metric's second half): the device trajectory against the oracle's on the same frames
+            traj_rmse = synth.ate_rmse(seq_gpu["poses"][:nseq], o_poses)
+            ate_gpu_n = synth.ate_rmse(seq_gpu["poses"][:nseq], seq_gpu["gt"][:nseq])
+            ate_cpu_n = synth.ate_rmse(o_poses, seq_gpu["gt"][:nseq])
             t_pyr, t_kf, t_trk = ovo.times()  # seconds in: pyramid builds, makeKeyframe, tracking + vote
             cpu_trk_only = nseq / t_trk
             # the reference's threading (system.cpp:96): IO thread builds pyramids, main thread tracks -- measured,
@@ -659,6 +725,11 @@ def main():
                                 "frames_per_s_runs": [n / t for t in runs], "frames": n,
                                 "keyframes": seq_gpu["keyframes"],
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
+                                # the oracle ran the same frames (its first `oracle_frames`): trajectory against trajectory, and
+                                # the difference of the two ATEs against the synthetic ground truth (north star: within 1 mm)
+                                "trajectory_rmse_gpu_vs_oracle_m": traj_rmse,
+                                "ate_difference_vs_oracle_m": (abs(ate_gpu_n - ate_cpu_n) if traj_rmse is not None else None),
+                                "ate_rmse_oracle_vs_ground_truth_m": ate_cpu_n, "oracle_frames": nseq,
                                 "rpe_rmse_per_frame": {"trans_m": rpe_t, "rot_rad": rpe_r},
                                 "cpu_oracle_frames_per_s_1core": cpu_seq,
                                 "cpu_oracle_frames_per_s_2core_pipelined": cpu_seq_2core,

@@ -56,6 +56,19 @@ def max_over_ranks(seconds, world, device="cpu"):
     return float(t.item())
 
 
+def gather_floats(value, world, device="cpu"):
+    """Every rank's float in rank order (on every rank): the per-rank step times of a bench line, so that a straggler
+    GPU shows in the first line of a real multi-GPU run instead of hiding inside the maximum."""
+    import torch
+    import torch.distributed as dist
+    if world == 1 and not _group_live():
+        return [float(value)]
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return [float(x) for x in out.cpu().tolist()]
+
+
 def ranks_seen(world, device="cpu"):
     """Every rank's id as the backend delivers it (one all_gather of one int64 per rank) plus the group's own idea of
     its size: a SCALE line carries this as proof that N ranks really took part.  -> (list of ranks, world size)."""

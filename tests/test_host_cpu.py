@@ -194,6 +194,8 @@ def _check_dry_run_line(rec, world, pairs, steps):
     assert rec["n_gpus"] == world and rec["steps"] == steps and rec["scaling"] == "weak"
     assert rec["config"]["global_pairs"] == world * pairs and rec["config"]["pairs_per_gpu"] == pairs
     assert rec["collective"]["ranks_seen"] == list(range(world)) and rec["collective"]["world_size"] == world
+    # every rank's own step time travels in the line (a straggler GPU must be visible in the first real N > 1 run)
+    assert len(rec["ms_per_step_per_rank"]) == world and max(rec["ms_per_step_per_rank"]) <= rec["ms_per_step"] * 1.0001
     assert rec["collective"]["bytes_per_rank"] == pairs * 96
 
 
