@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--edt-streams", type=int, default=0,
                     help="streams that run the keyframes' distance transforms the build leaves to its first consumer "
                          "(revo_batch_prepare); 0 = on the tracker's stream, in front of the grid")
+    ap.add_argument("--build-priority", type=int, default=0,
+                    help="HIP stream priority of the build stream(s) (-1 = high: the build chain is the critical one of the pipelined "
+                         "step and its kernels compete with the tracker streams' for free CUs)")
     ap.add_argument("--build-streams", type=int, default=1, help="experiment: builds of consecutive steps alternate over this many streams")
     ap.add_argument("--input-batches", type=int, default=3,
                     help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
@@ -358,9 +361,9 @@ def main():
     n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
     s_tracks = [s_track] + [torch.cuda.Stream(device=dev) for _ in range(n_tr - 1)]
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
-    s_build = torch.cuda.Stream(device=dev)
+    s_build = torch.cuda.Stream(device=dev, priority=a.build_priority)
     # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
-    s_builds = [s_build] + [torch.cuda.Stream(device=dev) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
+    s_builds = [s_build] + [torch.cuda.Stream(device=dev, priority=a.build_priority) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
     s_edts = [torch.cuda.Stream(device=dev) for _ in range(max(0, a.edt_streams) if nbuf >= 2 else 0)]
     torch.cuda.set_stream(s_track)
     stream = s_track.cuda_stream

@@ -111,7 +111,9 @@ struct EvalOut {
 #define REVO_MAX_WIDTH 2048  // EDT row staged in LDS as int32
 #define NMS_ROWS 6                  // output rows per k_canny_nms4 thread (4 pixels wide)
 #define EDT_ROW_PX 1280             // pixels per k_edt_rows workgroup (whole rows)
+#ifndef REVO_HYST_LDS_MAX
 #define REVO_HYST_LDS_MAX 158720    // dynamic LDS of k_hyst: the level's edge bitmap (+ candidate bitmap when both fit)
+#endif
 #ifndef TRACK_THREADS
 #define TRACK_THREADS 512
 #endif
