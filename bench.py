@@ -213,6 +213,10 @@ def main():
     ap.add_argument("--edt-streams", type=int, default=0,
                     help="streams that run the keyframes' distance transforms the build leaves to its first consumer "
                          "(revo_batch_prepare); 0 = on the tracker's stream, in front of the grid")
+    ap.add_argument("--track-priority", type=int, default=0, help="HIP stream priority of the tracker streams (-1 = high)")
+    ap.add_argument("--coll-on-track", action="store_true",
+                    help="enqueue the step's RCCL all_gather on the tracker's stream, right behind the grid, instead of on a stream "
+                         "of its own (one stream fewer for HIP to multiplex onto its hardware queues)")
     ap.add_argument("--build-priority", type=int, default=0,
                     help="HIP stream priority of the build stream(s) (-1 = high: the build chain is the critical one of the pipelined "
                          "step and its kernels compete with the tracker streams' for free CUs)")
@@ -355,11 +359,11 @@ def main():
     d_ress = [d_res_all[i * a.pairs * 96:(i + 1) * a.pairs * 96] for i in range(max(1, n_slots))]
     d_res = d_ress[0]
     d_res_side = torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev)  # side measurements write here
-    s_track = torch.cuda.Stream(device=dev)
+    s_track = torch.cuda.Stream(device=dev, priority=a.track_priority)
     # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
     # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
     n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
-    s_tracks = [s_track] + [torch.cuda.Stream(device=dev) for _ in range(n_tr - 1)]
+    s_tracks = [s_track] + [torch.cuda.Stream(device=dev, priority=a.track_priority) for _ in range(n_tr - 1)]
     s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
     s_build = torch.cuda.Stream(device=dev, priority=a.build_priority)
     # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
@@ -374,6 +378,8 @@ def main():
     timing, track_events = [False], []  # the dominant kernel is timed live in the timed steps (roofline)
     gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
     d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if use_group else None
+    # (--coll-on-track: gathers of consecutive steps run on different streams; each stream gathers into its own buffer)
+    d_alls = [torch.zeros_like(d_all) for _ in s_tracks] if (use_group and a.coll_on_track) else None
 
     def make_step(nb, tracks, builds, edts, outs, main):
         """One pipeline shape: `nb` batches in rotation, tracker grids alternating over `tracks`, builds over `builds`,
@@ -420,9 +426,11 @@ def main():
             if main and use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
                 # nothing on the device waits for it (the host reads the gathered records after the run), so it is off the
                 # tracker stream's chain; it is inside the timed region all the same (synchronize + barrier below)
-                s_coll.wait_event(ev_tracked[k])
-                with torch.cuda.stream(s_coll):
-                    gathered[0] = parallel.gather_records(d_out, world, out=d_all)
+                s_c = s_tr if a.coll_on_track else s_coll
+                if not a.coll_on_track:
+                    s_c.wait_event(ev_tracked[k])
+                with torch.cuda.stream(s_c):
+                    gathered[0] = parallel.gather_records(d_out, world, out=d_alls[t % len(tracks)] if a.coll_on_track else d_all)
         return step, counter
 
     step, counter = make_step(nbuf, s_tracks, s_builds, s_edts, d_ress, True)

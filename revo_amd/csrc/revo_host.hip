@@ -80,6 +80,7 @@ struct FrameSet {
   std::mutex edt_mu;
   std::atomic<bool> edt_pending{false};  // set by a batch build, cleared under edt_mu by whoever runs the EDT
   int edt_count = 0;              // keyframes: frames 0, 2, 4, ...
+  bool pts_pending = false;       // (REVO_PTS_DEFER) the tile-ordered edge lists of ALL frames were left to the same consumer too
   // whoever ran the deferred EDT recorded this on ITS stream: consumers (and the next build into these planes) on any other
   // stream order themselves behind it (`edt_pending == false` alone says "enqueued somewhere", not "visible here")
   hipEvent_t ev_edt = nullptr;
@@ -606,6 +607,7 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
     return REVO_OK;
   }
   if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, fs->ev_ready, 0));
+  if (fs->pts_pending) { launch_tile_points(c->geom, fs->p, fs->B, s); fs->pts_pending = false; }
   launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_edt, s));
@@ -1216,8 +1218,12 @@ static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   } else if (env_int("REVO_EDT_DEFER", 1, 0, 1)) {
     // the EDT of the keyframes is left to its first consumer (run_pending_edt): the batch's tracker launch runs it on ITS
     // stream, in front of the grid -- 97 us less on the build stream, which is the critical one of the pipelined step
-    launch_tile_points(g, b->fs->p, b->fs->B, s);
+    // REVO_PTS_DEFER=1 (experiment): the edge lists too -- they only depend on the edge maps and nothing on the build stream
+    // reads them; the build then ends with fillInEdges
+    const bool defer_pts = env_int("REVO_PTS_DEFER", 0, 0, 1) != 0;
+    if (!defer_pts) launch_tile_points(g, b->fs->p, b->fs->B, s);
     std::lock_guard<std::mutex> lk(b->fs->edt_mu);
+    b->fs->pts_pending = defer_pts;
     b->fs->edt_pending = true; b->fs->edt_count = b->n_pairs;
   } else {
     launch_tile_points(g, b->fs->p, b->fs->B, s);

@@ -797,16 +797,13 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
            hp[1] - hp[0], hp[5] - hp[1], ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], dbg_runs, dbg_sweeps, dbg_bands, (int)done);
 #endif
 }
-// only_flagged = 0: TWO workgroups per frame -- workgroup j < n_frames takes level 0 of frame j, workgroup n_frames + j the other
-// levels of frame j one after the other (their sum costs less than a level 0).  Every workgroup owns a CU's whole LDS, and
-// the tracker grids of the pipelined step leave few CUs without one of theirs (whose registers k_hyst cannot share): one
-// workgroup per (level, frame) asked for 256 such CUs per 64 frames, this asks for 128 (in the pipelined step the launch took
-// 87-140 us for its 80).  Level-0 workgroups come first in the grid (ids go round-robin over the 8 XCDs; heaviest first).
-// only_flagged = 1 (launch D of the banded path): a few workgroups share the (level, frame) pairs a band handed over --
-// normally none, and then the launch costs a flag sweep.
-#ifndef REVO_HYST_GROUPED
-#define REVO_HYST_GROUPED 1
-#endif
+// n_items = levels x frames of the launch.  only_flagged = 0: one workgroup per (level, frame), level-major (workgroup ids go
+// round-robin over the 8 XCDs: with (level, frame) = (x, z) every level-0 workgroup -- the expensive ones -- had an id that is
+// a multiple of n_levels = 4, i.e. all of them sat on XCDs 0 and 4).  only_flagged = 1 (launch D of the banded path): a few
+// workgroups share the (level, frame) pairs a band handed over -- normally none, and then the launch costs a flag sweep.
+// (Measured in round 4 and not kept, profiles/r04_ab_hyst_grouping_priority.txt: two workgroups per frame -- level 0 / the
+// other levels one after the other -- so that the launch asks for 128 whole-LDS CUs instead of 256: 84.4 k against 87.2 k
+// frames/s; a 512-thread, 144 KB variant that fits next to a tracker workgroup: 72 k, the kernel alone is 35 % slower.)
 template <bool C_IN_LDS>
 __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl, int only_flagged, int n_frames) {
   extern __shared__ uint32_t s_mem[];
@@ -819,17 +816,6 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
       if (pl.need_full[(g.frame0 + item % n_frames) * REVO_L + item / n_frames]) s_any = 1;
     __syncthreads();
     if (!s_any) return;
-  }
-  if (REVO_HYST_GROUPED && !only_flagged) {
-    for (int grp = blockIdx.x; grp < 2 * n_frames; grp += gridDim.x) {
-      const int f = g.frame0 + grp % n_frames;
-      const int la = grp < n_frames ? 0 : 1, lb = grp < n_frames ? 1 : g.n_levels;
-      for (int l = la; l < lb; ++l) {
-        hyst_level<C_IN_LDS>(g, pl, l, f, s_mem);
-        __syncthreads();
-      }
-    }
-    return;
   }
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int l = item / n_frames;
@@ -2085,7 +2071,7 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
     if (g.any_banded) hipLaunchKernelGGL(k_hyst_seam, dim3(g.n_levels * B), dim3(HS_THREADS), seam_lds, s, g, p);
     hipLaunchKernelGGL(k_hyst_out, dim3(g.total_bands * B), dim3(HO_THREADS), out_lds, s, g, p);
   }
-  const int n_wg = only_flagged ? std::min(32, g.n_levels * B) : (REVO_HYST_GROUPED ? (g.n_levels > 1 ? 2 : 1) * B : g.n_levels * B);
+  const int n_wg = only_flagged ? std::min(32, g.n_levels * B) : g.n_levels * B;
   if (ec_bytes + 4096 <= REVO_HYST_LDS_MAX)  // candidate bitmap + union-find labels in LDS: all of it (one workgroup per CU anyway)
     hipLaunchKernelGGL(k_hyst<true>, dim3(n_wg), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p, only_flagged, B);
   else  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
