@@ -73,8 +73,10 @@ typedef struct revo_pyr_settings {
   int32_t hist_patch[REVO_MAX_LEVELS];
 } revo_pyr_settings;
 /* Geometry accepted by revo_ctx_create (anything else is REVO_ERR_INVALID_ARG with a message): width a
- * multiple of 4*2^(levels-1) and <= 2048, height a multiple of 2^(levels-1) and <= 1024, at most
- * REVO_MAX_LEVELS levels, every level a multiple of 16 pixels (640x480: up to 5 levels, 1280x960: 6), hist_patch[l] dividing into <= 128 tiles per row. */
+ * multiple of 4*2^(levels-1) and <= 2048, height a multiple of 2^(levels-1) and <= 2048, at most 2048 tiles of 32 x 32
+ * pixels (1920x1080 and 1280x1024 fit), at most REVO_MAX_LEVELS levels, every level a multiple of 16 pixels (640x480: up to
+ * 5 levels, 1280x960: 6), hist_patch[l] dividing into <= 128 tiles per row.  The reference itself truncates any size
+ * (camerapyr.h:98-103). */
 
 /* OptimizerSettings, optimizer.h:42-112 (only the fields the hot path reads). */
 typedef struct revo_opt_settings {

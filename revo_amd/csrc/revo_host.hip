@@ -179,8 +179,11 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   const int L = s.pyr_min_lvl - s.pyr_max_lvl + 1;  // camerapyr.h:68-71
   if (s.pyr_max_lvl != 0) { *why = "pyr_max_lvl must be 0 (the reference indexes per-level vectors by level)"; return -1; }
   if (L < 1 || L > REVO_L) { *why = "1..6 pyramid levels supported"; return -1; }
-  if (s.width <= 0 || s.height <= 0 || s.width > REVO_MAX_WIDTH || s.height > 1024) {
-    *why = "image size must be within 2048 x 1024 (and every level's (height + 2) x ceil(width/32) edge bitmap within 155 KB of LDS: 1280 x 960 and 1920 x 640 fit, 1280 x 1024 does not)"; return -1;
+  // the reference truncates whatever it is given (camerapyr.h:98-103); here: up to 2048 x 2048 (the EDT's LDS rows, the
+  // 64 x 32-row chunks of the column walks) with at most 2048 tiles of 32 x 32 pixels per level (k_tile_count)
+  if (s.width <= 0 || s.height <= 0 || s.width > REVO_MAX_WIDTH || s.height > 2048 ||
+      ((s.width + 31) / 32) * ((s.height + 31) / 32) > 2048) {
+    *why = "image size must be within 2048 x 2048 and 2048 tiles of 32 x 32 pixels (1920 x 1080 fits, 2048 x 1536 does not)"; return -1;
   }
   if (s.width % (4 << (L - 1)) || s.height % (1 << (L - 1))) {
     *why = "width must be a multiple of 4*2^(levels-1) and height of 2^(levels-1)"; return -1;
@@ -217,8 +220,8 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
     v.chunk_rows = 32; v.nchunk = (v.h + 31) / 32;
     v.wpr = (v.w + 31) / 32;
     v.nms_block_base = tile; tile += (8 * v.wpr * ((v.h + NMS_ROWS - 1) / NMS_ROWS) + 255) / 256;
-    // the level's edge bitmap must fit the LDS of one workgroup (k_hyst)
-    if (((size_t)(v.h + 2) * v.wpr + 2) * 4 > REVO_HYST_LDS_MAX) { *why = "image too large: (height + 2) x ceil(width/32) bitmap words must fit 155 KB of LDS"; return -1; }
+    // (a level whose edge bitmap does not fit one workgroup's LDS takes the banded hysteresis; its last resort keeps the bitmap
+    // in the scratch plane: launch_hyst)
     v.pix_base = pix; pix += v.npix;
     v.edt_rows = std::max(1, EDT_ROW_PX / v.w);
     v.edt_block_base = row; row += (v.h + v.edt_rows - 1) / v.edt_rows;

@@ -388,8 +388,13 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
 #define HP(i)
 #define HA(i)
 #endif
-template <bool C_IN_LDS>
+// E_GLOBAL (only with C_IN_LDS = false): the level's edge bitmap does not fit a CU's LDS either (levels beyond ~1280 x 990):
+// E lives in the (level, frame)'s scratch plane in HBM / L2 -- same layout, same code; the workgroup's own stores are visible
+// to its own loads after a barrier.  This is the exact last resort of the banded path on very large levels (a band whose runs
+// exceed its label space): slow, correct, rare.
+template <bool C_IN_LDS, bool E_GLOBAL = false>
 __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& pl, const int l, const int f, uint32_t* s_mem) {
+  static_assert(!(C_IN_LDS && E_GLOBAL), "the candidate bitmap is in LDS only when the edge bitmap is");
 #ifdef REVO_HYST_PROFILE
   long long hp[12], ha[8], hlast = 0;
   for (int i = 0; i < 12; ++i) hp[i] = 0;
@@ -411,7 +416,8 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
   // flag pass.  That keeps such a level in ONE band (two sweeps over three bands cost those frames -- and with
   // them the whole launch -- twice the time); levels with fewer runs never re-read anything.
   uint32_t* Cl = s_mem;
-  uint32_t* Ebase = C_IN_LDS ? s_mem + (REVO_HYST_LDS_MAX / 4 - e_words) : s_mem;
+  uint32_t* Ebase = C_IN_LDS ? s_mem + (REVO_HYST_LDS_MAX / 4 - e_words)
+                  : (E_GLOBAL ? reinterpret_cast<uint32_t*>(pl.scratch[l] + (size_t)f * g.lv[l].npix) : s_mem);
   uint32_t* E = Ebase + 1;                       // E[(r + 1) * pitch + c] = E(r, c), r = -1 .. h
   const uint2* cs = pl.cs[l] + (size_t)f * h * wpr;
   const int tid = threadIdx.x;
@@ -804,7 +810,7 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
 // (Measured in round 4 and not kept, profiles/r04_ab_hyst_grouping_priority.txt: two workgroups per frame -- level 0 / the
 // other levels one after the other -- so that the launch asks for 128 whole-LDS CUs instead of 256: 84.4 k against 87.2 k
 // frames/s; a 512-thread, 144 KB variant that fits next to a tracker workgroup: 72 k, the kernel alone is 35 % slower.)
-template <bool C_IN_LDS>
+template <bool C_IN_LDS, bool E_GLOBAL = false>
 __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl, int only_flagged, int n_frames) {
   extern __shared__ uint32_t s_mem[];
   const int n_items = g.n_levels * n_frames;
@@ -821,7 +827,7 @@ __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl
     const int l = item / n_frames;
     const int f = g.frame0 + item % n_frames;
     if (only_flagged && !pl.need_full[f * REVO_L + l]) continue;
-    hyst_level<C_IN_LDS>(g, pl, l, f, s_mem);
+    hyst_level<C_IN_LDS, E_GLOBAL>(g, pl, l, f, s_mem);
     __syncthreads();
   }
 }
@@ -1335,7 +1341,7 @@ __device__ __forceinline__ bool depth_ok(float Z, float dmin, float dmax) {
 #ifndef CW_LANES_COUNT
 #define CW_LANES_COUNT 8               // count pass: 512 threads x 48 VGPRs fit next to a resident tracker workgroup (176 free
 #endif                                 // VGPRs per SIMD); 1024 x 48 do not, and the pass then waited for the tracker's CUs
-#define CW_MAXCHUNK 32                 // height <= 1024
+#define CW_MAXCHUNK 64                 // height <= 2048 (accessor-only kernel since round 3: its LDS footprint no longer matters)
 #define CW_STAGE 4096                  // points staged in LDS per strip (64 KB); denser strips store directly
 template <bool WRITE>
 __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT)) k_compact_walk(PyrGeom g, FramePlanes pl) {
@@ -1452,10 +1458,10 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
     int total;
     {
       constexpr int NT = CW_COLS * CW_LANES;  // (the write pass; this branch is dead code in the count instantiation)
-      static_assert(CW_COLS * CW_MAXCHUNK <= 2 * NT, "two slots per thread");
-      const int i0 = 2 * tid, i1 = 2 * tid + 1;
-      const int c0 = i0 < nslots ? s_cnt[i0] : 0, c1 = i1 < nslots ? s_cnt[i1] : 0;
-      const int sum = c0 + c1;
+      static_assert(CW_COLS * CW_MAXCHUNK <= 4 * NT, "four slots per thread");
+      int cs4[4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { cs4[q] = 4 * tid + q < nslots ? s_cnt[4 * tid + q] : 0; sum += cs4[q]; }
       int incl = sum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -1470,9 +1476,12 @@ __global__ void __launch_bounds__(CW_COLS * (WRITE ? CW_LANES : CW_LANES_COUNT))
       total = wv;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); total += __shfl_xor(total, o); }
-      const int run = base + pre + incl - sum;
-      if (i0 < nslots) s_cnt[i0] = run;
-      if (i1 < nslots) s_cnt[i1] = run + c0;
+      int run = base + pre + incl - sum;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (4 * tid + q < nslots) s_cnt[4 * tid + q] = run;
+        run += cs4[q];
+      }
       __syncthreads();
     }
     // (npts is NOT stored here: k_tile_count wrote the same count during the build, and this accessor-only walk may run
@@ -1794,15 +1803,16 @@ __global__ void __launch_bounds__(1024) k_pcl_scan(int* chunk, int n, int* total
 // keeps their edge bits in a 32-bit mask: nearest edge above/below = clz / ffs on the mask, or the
 // LDS carry (last/first edge row of the other groups).  One edge read, one g^2 write per pixel.
 #define EDT_THREADS 1024
+#define EDT_COL_GROUPS(h) ((h) > 1024 ? 64 : ((h) > 512 ? 32 : 16))  // row groups of <= 32 rows per column (heights <= 2048)
 __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes pl, int f0, int fstride, int nframes) {
   __shared__ int s_first[EDT_THREADS];  // [group][column]: first edge row of the group's segment (or +INF)
   __shared__ int s_last[EDT_THREADS];   // last edge row of the segment (or -INF)
   // 1-D grid, frame fastest (the strips of a frame share one XCD's L2, see k_compact_walk)
   const int f = f0 + (blockIdx.x % nframes) * fstride;
-  // decode (level, strip); taller levels use 32 groups x 32 columns, the others 16 x 64
+  // decode (level, strip); taller levels use 32 groups x 32 columns (64 x 16 above 1024 rows), the others 16 x 64
   int l = 0, sidx = blockIdx.x / nframes, ngroups = 16, ncols = 64;
   for (int k = 0; k < g.n_levels; ++k) {
-    ngroups = g.lv[k].h > 512 ? 32 : 16;
+    ngroups = EDT_COL_GROUPS(g.lv[k].h);
     ncols = EDT_THREADS / ngroups;
     const int ns = (g.lv[k].w + ncols - 1) / ncols;
     if (sidx < ns) { l = k; break; }
@@ -1811,7 +1821,7 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
   const LevelGeom& lv = g.lv[l];
   const int col = threadIdx.x % ncols, grp = threadIdx.x / ncols;
   const int x = sidx * ncols + col;
-  const int rpg = (lv.h + ngroups - 1) / ngroups;  // <= 32 (height <= 1024)
+  const int rpg = (lv.h + ngroups - 1) / ngroups;  // <= 32 (height <= 2048)
   const int yb = min(lv.h, grp * rpg), ye = min(lv.h, yb + rpg);
   const bool in = x < lv.w;
   const uint8_t* edges = pl.edges[l] + (size_t)f * lv.npix;
@@ -1840,7 +1850,7 @@ __global__ void __launch_bounds__(EDT_THREADS) k_edt_cols(PyrGeom g, FramePlanes
   uint16_t* gd = reinterpret_cast<uint16_t*>(pl.scratch[l]) + (size_t)f * lv.npix;  // vertical distance, 0xffff = no edge in the column
   // walking down the segment: the distance to the nearest edge above grows by one per row and drops to 0 on an edge; the one
   // below is ffs on what is left of the mask, or the carry from the groups below.  "No edge" is a distance beyond any height
-  // (the rows of a level are <= 1024), so the sums below cannot wrap and everything >= 0xffff is written as 0xffff.
+  // (the rows of a level are <= 2048), so the sums below cannot wrap and everything >= 0xffff is written as 0xffff.
   const int FAR = 1 << 20;
   int du = (above <= -EDT_INF) ? FAR : (yb - above);      // of row yb - 1, plus one
   const int dbelow = (below >= EDT_INF) ? FAR : (below - yb);
@@ -2074,8 +2084,10 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   const int n_wg = only_flagged ? std::min(32, g.n_levels * B) : g.n_levels * B;
   if (ec_bytes + 4096 <= REVO_HYST_LDS_MAX)  // candidate bitmap + union-find labels in LDS: all of it (one workgroup per CU anyway)
     hipLaunchKernelGGL(k_hyst<true>, dim3(n_wg), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p, only_flagged, B);
-  else  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
+  else if (e_bytes <= REVO_HYST_LDS_MAX)  // big levels: only the edge bitmap lives in LDS, the (constant) candidate words are re-read through L1/L2
     hipLaunchKernelGGL(k_hyst<false>, dim3(n_wg), dim3(HYST_THREADS), e_bytes, s, g, p, only_flagged, B);
+  else  // very big levels (beyond ~1280 x 990): the edge bitmap in the scratch plane -- the last resort behind the bands
+    hipLaunchKernelGGL((k_hyst<false, true>), dim3(n_wg), dim3(HYST_THREADS), 16, s, g, p, only_flagged, B);
 }
 
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
@@ -2118,7 +2130,7 @@ void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int l
 void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {
   int strips = 0;
   for (int l = 0; l < g.n_levels; ++l) {
-    const int ncols = EDT_THREADS / (g.lv[l].h > 512 ? 32 : 16);
+    const int ncols = EDT_THREADS / EDT_COL_GROUPS(g.lv[l].h);
     strips += (g.lv[l].w + ncols - 1) / ncols;
   }
   hipLaunchKernelGGL(k_edt_cols, dim3(strips * count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride, count);

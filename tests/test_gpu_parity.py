@@ -190,10 +190,13 @@ def test_dense_edges_640_take_the_unstaged_compaction_path(api, ro):
     assert gp.return3DEdges(0).shape[0] > 10 * 4096  # > 4096 per strip on average (10 strips)
 
 
-@pytest.mark.parametrize("w,h,levels", [(64, 48, 2), (136, 88, 2), (200, 120, 2), (328, 248, 2), (72, 40, 1), (1120, 624, 3)])
+@pytest.mark.parametrize("w,h,levels", [(64, 48, 2), (136, 88, 2), (200, 120, 2), (328, 248, 2), (72, 40, 1), (1120, 624, 3),
+                                        (1280, 1024, 3), (1920, 1080, 4)])
 def test_unusual_sizes_bit_exact(api, ro, w, h, levels):
     """Widths that are not multiples of the 64-pixel tiles / strips, heights that are not multiples of the
-    16-row tiles or 32-row chunks, on smooth random images with depth holes: every plane bit-exact."""
+    16-row tiles or 32-row chunks, on smooth random images with depth holes: every plane bit-exact.  1280 x 1024 and
+    1920 x 1080 (round 4): level 0's edge bitmap no longer fits one workgroup's LDS (banded hysteresis only), and 1080 rows
+    need 34 row chunks / 64 row groups in the column walks (the reference takes any size: camerapyr.h:98-103)."""
     import scipy.ndimage as ndi
     s = ImgPyramidSettings.scaled(w, h, levels, hist_patch=(0, 0, 0, 0, 0, 0))
     r = np.random.default_rng(w * 1000 + h)
@@ -210,6 +213,23 @@ def test_unusual_sizes_bit_exact(api, ro, w, h, levels):
     assert gp.return3DEdges(0).shape[0] > 0
     for dense in (False, True):
         assert_same("size_pcl", gp.generateColoredPcl(levels - 1, dense), op.generateColoredPcl(levels - 1, dense))
+
+
+def test_large_level_last_resort_hysteresis(api, ro):
+    """Dense noise at 1280 x 1024: the bands' weak runs exceed their label space, so the (level, frame) falls through to the
+    whole-level flood fill -- whose edge bitmap (164 KB) no longer fits a CU's LDS and lives in the scratch plane
+    (k_hyst<false, true>).  Edges, lists and DT bit-exact like everywhere else."""
+    s = ImgPyramidSettings.scaled(1280, 1024, 3, hist_patch=(20, 10, 5, 0, 0, 0))
+    rng = np.random.default_rng(5)
+    bgr = rng.integers(0, 256, (1024, 1280, 3), dtype=np.uint8)
+    depth = rng.uniform(0.0, 6.0, (1024, 1280)).astype(np.float32)
+    depth[rng.uniform(0, 1, depth.shape) < 0.2] = 0.0
+    cam = api.CameraPyr(s)
+    gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+    op = ro.Pyramid(s, bgr, depth)
+    gp.makeKeyframe()
+    op.makeKeyframe()
+    compare_pyramid("noise1280x1024", gp, op, s, True)
 
 
 def test_u16_depth_entry_point(api, ro):
