@@ -80,7 +80,8 @@ struct FrameSet {
   std::mutex edt_mu;
   std::atomic<bool> edt_pending{false};  // set by a batch build, cleared under edt_mu by whoever runs the EDT
   int edt_count = 0;              // keyframes: frames 0, 2, 4, ...
-  bool pts_pending = false;       // (REVO_PTS_DEFER) the tile-ordered edge lists of ALL frames were left to the same consumer too
+  bool pts_pending = false;       // (REVO_DEFER >= 2) the tile-ordered edge lists of ALL frames were left to the same consumer too
+  bool hyst_pending = false;      // (REVO_DEFER = 3) ... and hysteresis + fill-in: the build stopped behind the Canny NMS
   // whoever ran the deferred EDT recorded this on ITS stream: consumers (and the next build into these planes) on any other
   // stream order themselves behind it (`edt_pending == false` alone says "enqueued somewhere", not "visible here")
   hipEvent_t ev_edt = nullptr;
@@ -464,7 +465,7 @@ static void frameset_destroy(FrameSet* fs) {
 // with_points = false: stops after fillInEdges; the caller enqueues launch_tile_points itself (batches run it next to the EDT)
 static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
                           const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false,
-                          bool with_points = true, int frame0 = 0, int nframes = -1) {
+                          bool with_points = true, int frame0 = 0, int nframes = -1, bool with_hyst = true) {
   PyrGeom g = c->geom;
   g.frame0 = frame0;
   const int B = nframes < 0 ? fs->B : nframes;
@@ -472,6 +473,7 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
   launch_gray_depth(g, fs->p, d_bgr, d_depth_f32, d_depth_u16, alpha, B, s);
   for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, B, s);
   launch_canny_nms(g, fs->p, B, s);
+  if (!with_hyst) return;  // (batches with REVO_DEFER = 3: the rest is left to the first consumer, run_pending_edt)
   launch_hyst(g, fs->p, B, s);
   launch_fill(g, fs->p, B, s);
   if (with_points) launch_tile_points(g, fs->p, B, s);  // the tracker's (tile-ordered) edge list; the reference's order is built on demand
@@ -610,6 +612,7 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
     return REVO_OK;
   }
   if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, fs->ev_ready, 0));
+  if (fs->hyst_pending) { launch_hyst(c->geom, fs->p, fs->B, s); launch_fill(c->geom, fs->p, fs->B, s); fs->hyst_pending = false; }
   if (fs->pts_pending) { launch_tile_points(c->geom, fs->p, fs->B, s); fs->pts_pending = false; }
   launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
   HIPCHECK(hipGetLastError());
@@ -1206,6 +1209,10 @@ static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
   return REVO_OK;
 }
 
+static int batch_defer_level() {
+  if (!env_int("REVO_EDT_DEFER", 1, 0, 1)) return 0;
+  return env_int("REVO_DEFER", env_int("REVO_PTS_DEFER", 0, 0, 1) ? 2 : 1, 0, 3);
+}
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   const PyrGeom& g = b->ctx->geom;
   if (b->side) {
@@ -1218,15 +1225,17 @@ static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
     HIPCHECK(hipEventRecord(b->ev_join, b->side));
     b->fs->ev_aux = b->ev_join; b->fs->has_aux = true;
     launch_tile_points(g, b->fs->p, b->fs->B, s);
-  } else if (env_int("REVO_EDT_DEFER", 1, 0, 1)) {
-    // the EDT of the keyframes is left to its first consumer (run_pending_edt): the batch's tracker launch runs it on ITS
-    // stream, in front of the grid -- 97 us less on the build stream, which is the critical one of the pipelined step
-    // REVO_PTS_DEFER=1 (experiment): the edge lists too -- they only depend on the edge maps and nothing on the build stream
-    // reads them; the build then ends with fillInEdges
-    const bool defer_pts = env_int("REVO_PTS_DEFER", 0, 0, 1) != 0;
-    if (!defer_pts) launch_tile_points(g, b->fs->p, b->fs->B, s);
+  } else if (batch_defer_level() >= 1) {
+    // Work left to the batch's first consumer (run_pending_edt: the tracker launch on ITS stream, revo_batch_prepare on a
+    // stream of the caller's choice, an accessor, revo_batch_sync) -- the build stream is the critical chain of the
+    // pipelined step.  REVO_DEFER = 1: the keyframes' EDT (97 us less on the build stream; round 3);  2: the edge lists of all
+    // frames too (they only depend on the edge maps and nothing on the build stream reads them);  3: hysteresis + fill-in as
+    // well (the build ends behind the Canny NMS).  REVO_EDT_DEFER=0 / REVO_DEFER=0: nothing is deferred.
+    const int lvl = batch_defer_level();
+    if (lvl < 2) launch_tile_points(g, b->fs->p, b->fs->B, s);
     std::lock_guard<std::mutex> lk(b->fs->edt_mu);
-    b->fs->pts_pending = defer_pts;
+    b->fs->hyst_pending = lvl >= 3;
+    b->fs->pts_pending = lvl >= 2;
     b->fs->edt_pending = true; b->fs->edt_count = b->n_pairs;
   } else {
     launch_tile_points(g, b->fs->p, b->fs->B, s);
@@ -1248,7 +1257,7 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }     // ... or its deferred EDT, on whichever stream ran it
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }              // ... and its tracker grid still reads lists and DT planes
   // (Measured and not kept: the two halves of the batch as two concurrent kernel chains -- 78.4 k -> 70.5 k frames/s.)
-  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false);
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || batch_defer_level() < 3);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
@@ -1317,7 +1326,8 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }
-  enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false);
+  enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false, 0, -1,
+                b->side || batch_defer_level() < 3);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
