@@ -187,9 +187,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pairs", type=int, default=32, help="frame-pairs per GPU per step")
-    ap.add_argument("--buffers", type=int, default=3,
-                    help="batches in rotation: 3 = the build of step k+2 next to the tracker grids of steps k+1 and k (the library's "
-                         "resident gate keeps two tracker grids in flight); 2 = round 2's double buffering")
+    ap.add_argument("--buffers", type=int, default=4,
+                    help="batches in rotation: 4 = build(k+3) | edge lists + EDT(k+2) | tracker grids of steps k+1 and k (the library's "
+                         "resident gate keeps two tracker grids in flight); 3 = round 3's shape; 2 = round 2's double buffering")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
@@ -210,13 +210,15 @@ def main():
     ap.add_argument("--track-streams", type=int, default=2,
                     help="streams the tracker launches alternate over (the library keeps REVO_TRACK_DEPTH grids in flight, "
                          "default 2; more streams than that buy nothing)")
-    ap.add_argument("--edt-streams", type=int, default=0,
-                    help="streams that run the keyframes' distance transforms the build leaves to its first consumer "
-                         "(revo_batch_prepare); 0 = on the tracker's stream, in front of the grid")
+    ap.add_argument("--edt-streams", type=int, default=1,
+                    help="streams that run what the build leaves to its first consumer (revo_batch_prepare: the edge lists and the "
+                         "keyframes' distance transforms, REVO_DEFER); 0 = on the tracker's stream, in front of the grid (round 3)")
     ap.add_argument("--track-priority", type=int, default=0, help="HIP stream priority of the tracker streams (-1 = high)")
-    ap.add_argument("--coll-on-track", action="store_true",
-                    help="enqueue the step's RCCL all_gather on the tracker's stream, right behind the grid, instead of on a stream "
-                         "of its own (one stream fewer for HIP to multiplex onto its hardware queues)")
+    ap.add_argument("--coll-own-stream", dest="coll_on_track", action="store_false",
+                    help="enqueue the step's RCCL all_gather on a stream of its own instead of on the tracker's stream, right behind "
+                         "the grid (default: HIP multiplexes its streams onto four hardware queues, and a fifth active stream ends up "
+                         "behind another one's kernels: profiles/r04_ab_pipeline_shapes.txt / r04_ab_queues_defer.txt)")
+    ap.set_defaults(coll_on_track=True)
     ap.add_argument("--build-priority", type=int, default=0,
                     help="HIP stream priority of the build stream(s) (-1 = high: the build chain is the critical one of the pipelined "
                          "step and its kernels compete with the tracker streams' for free CUs)")
@@ -615,7 +617,7 @@ def main():
             "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
                                                         "earlier ones; consecutive tracker grids on %d stream(s), ordered by the library's "
                                                         "resident gate (at most %s in flight)%s" % (nbuf, a.pairs, len(s_tracks), os.environ.get("REVO_TRACK_DEPTH", "2"),
-                                                                                                  "; the keyframes' distance transforms on %d stream(s) of their own" % len(s_edts) if s_edts else "")),
+                                                                                                  "; what the build leaves to its first consumer (REVO_DEFER=%s: 1 = the keyframes' EDT, 2 = + the edge lists, 3 = + hysteresis) on %d stream(s) of its own; the RCCL gather %s" % (os.environ.get("REVO_DEFER", "2"), len(s_edts), "on the tracker's stream, behind the grid" if a.coll_on_track else "on its own stream") if s_edts else "")),
             "batches_in_rotation": nbuf, "pairs_resident": nbuf * a.pairs,
         },
         "roofline": {

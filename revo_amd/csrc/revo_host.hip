@@ -1211,7 +1211,9 @@ static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
 
 static int batch_defer_level() {
   if (!env_int("REVO_EDT_DEFER", 1, 0, 1)) return 0;
-  return env_int("REVO_DEFER", env_int("REVO_PTS_DEFER", 0, 0, 1) ? 2 : 1, 0, 3);
+  // default 2 (round 4: 87.1 k -> 95.6 k frames/s together with a stream of their own for the deferred kernels and four batches
+  // in rotation, profiles/r04_ab_defer_levels.txt; 3 was measured too: 92.8 k)
+  return env_int("REVO_DEFER", 2, 0, 3);
 }
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   const PyrGeom& g = b->ctx->geom;
