@@ -292,10 +292,11 @@ int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const uint16_t* d_
                          double depth_scale_factor, void* stream);
 int revo_batch_track_only(revo_batch* b, const float* h_init_RT,
                           revo_pair_result* d_results, void* stream);
-/* Runs, on `stream`, whatever part of the last build was left to the batch's first consumer (today: the keyframes'
- * distance transforms, keyframe.cpp:43-58 -- the build leaves them to the tracker's stream so the build stream is free
- * for the next batch).  revo_batch_track_only does this itself; call it first only to keep that work outside a timed
- * tracker launch.  No-op when nothing is pending. */
+/* Runs, on `stream`, whatever part of the last build was left to the batch's first consumer (default: the 3-D edge lists,
+ * imgpyramidrgbd.cpp:199-226, and the keyframes' distance transforms, imgpyramidrgbd.cpp:231-252 -- the build stream is the
+ * critical one of a pipelined caller).  revo_batch_track_only does this itself on ITS stream; call this first to run that work
+ * on another stream (the library orders every later consumer and the next build of the batch behind it) or to keep it outside a
+ * timed tracker launch.  On a stream other than the build's it waits for the build.  No-op when nothing is pending. */
 int revo_batch_prepare(revo_batch* b, void* stream);
 int revo_batch_sync(revo_batch* b, void* stream);
 /* Pyramid view of frame f of the batch (owned by the batch). */
