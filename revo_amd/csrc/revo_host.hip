@@ -613,13 +613,10 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
   }
   if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, fs->ev_ready, 0));
   if (fs->hyst_pending) { launch_hyst(c->geom, fs->p, fs->B, s); launch_fill(c->geom, fs->p, fs->B, s); fs->hyst_pending = false; }
-  // the edge lists and the EDT do not depend on each other.  REVO_AUX_ORDER=1: EDT first -- on a stream of its own this work runs
-  // next to the NEXT batch's build, whose first kernels (gray, pyrDown) are memory-bound like the edge lists and whose later ones
-  // (NMS) are VALU-bound like the EDT's row pass
-  static const int aux_order = env_int("REVO_AUX_ORDER", 0, 0, 1);
-  if (aux_order == 1) launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
+  // (the edge lists and the EDT do not depend on each other; running the EDT first -- next to the memory-bound first kernels of
+  // the following build instead of its VALU-bound NMS -- was measured equal: profiles/r04_ab_aux_order.txt)
   if (fs->pts_pending) { launch_tile_points(c->geom, fs->p, fs->B, s); fs->pts_pending = false; }
-  if (aux_order == 0) launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
+  launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_edt, s));
   fs->has_edt = true;
