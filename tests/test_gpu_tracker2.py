@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from revo_amd import synth  # noqa: E402
-from revo_amd.settings import ImgPyramidSettings, OptimizerSettings, TrackerSettings  # noqa: E402
+from revo_amd.settings import ImgPyramidSettings, OptimizerSettings, TrackerSettings, PLANE_DT  # noqa: E402
 
 ROT_TOL = 1e-4   # rad
 TRANS_TOL = 1e-4  # m
@@ -346,3 +346,52 @@ def test_tracker_grids_on_two_streams_overlap_under_the_resident_gate(api, ro):
     torch.cuda.synchronize()
     for t in range(3 * rounds):
         assert outs[t].cpu().numpy().tobytes() == ref[t % 3], "step %d differs from the batch alone" % t
+
+
+def test_three_stage_pipeline_with_a_stream_for_the_deferred_kernels(api, ro):
+    """Round 4: the shape bench.py measures -- four batches in rotation, builds on one stream, what a build leaves to its
+    first consumer (edge lists + keyframe EDT, REVO_DEFER=2) on a stream of its own through revo_batch_prepare, tracker grids
+    alternating over two streams.  The library orders the tracker launch, the accessors and the NEXT build of a batch behind
+    the prepared work by its own per-FrameSet event: the caller only hands over the build's event.  Every record
+    of every round must equal the record the same batch produces alone on one stream, bit for bit."""
+    import torch
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    n, nb = 8, 4
+    dev = torch.device("cuda", 0)
+    bts, inputs, ref = [], [], []
+    for b in range(nb):
+        pairs = [synth.make_pair(700 + 10 * b + i, s) for i in range(n)]
+        bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).to(dev)
+        dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).to(dev)
+        bt = api.BatchTracker(cam, n)
+        res = torch.zeros(n * 96, dtype=torch.uint8, device=dev)
+        bt.track(bgr.data_ptr(), dep.data_ptr(), res.data_ptr())
+        bt.sync()
+        bts.append(bt); inputs.append((bgr, dep)); ref.append(res.cpu().numpy().tobytes())
+        assert all(r["flags"] & (2 | 4 | 8) == 0 for r in api.results_from_buffer(ref[-1], n))
+    s_trk = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    s_build, s_aux = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    rounds = 5
+    outs = [torch.zeros(n * 96, dtype=torch.uint8, device=dev) for _ in range(nb * rounds)]
+    built = [torch.cuda.Event() for _ in range(nb)]
+    tracked = [torch.cuda.Event() for _ in range(nb)]
+    for t in range(nb * rounds):
+        b, st = t % nb, s_trk[t % 2]
+        s_build.wait_event(tracked[b])
+        bts[b].build(inputs[b][0].data_ptr(), inputs[b][1].data_ptr(), stream=s_build.cuda_stream)
+        built[b].record(s_build)
+        s_aux.wait_event(built[b])
+        bts[b].prepare(stream=s_aux.cuda_stream)
+        # NO event from the aux stream to the tracker stream: the library's own event must order the grid behind the prepared work
+        bts[b].track_only(outs[t].data_ptr(), stream=st.cuda_stream)
+        tracked[b].record(st)
+    torch.cuda.synchronize()
+    for t in range(nb * rounds):
+        assert outs[t].cpu().numpy().tobytes() == ref[t % nb], "step %d differs from the batch alone" % t
+    # an accessor on a batch view after the pipelined rounds sees finished lists and DT planes
+    v = bts[0].frame(0, s)
+    o = ro.Pyramid(s, inputs[0][0][0].cpu().numpy(), inputs[0][1][0].cpu().numpy())
+    o.makeKeyframe()
+    assert np.array_equal(v.returnDistTransform(0), o.read(PLANE_DT, 0))
