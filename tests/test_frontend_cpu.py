@@ -103,3 +103,18 @@ def test_ate_and_rpe_evaluators():
     assert synth.ate_rmse(est, gt) > 0.02
     rt5, _ = synth.rpe_rmse(est, gt, delta=5)
     assert 0.03 < rt5 < 0.06
+
+
+def test_make_pairs_renders_the_same_pairs_on_several_cores():
+    """synth.make_pairs (spawned workers: GPU tests call it from a process that holds an initialised HIP runtime) returns exactly
+    what make_pair returns seed by seed."""
+    import numpy as np
+    from revo_amd import synth
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
+    many = synth.make_pairs([11, 12, 13], s, workers=2)
+    for seed, got in zip([11, 12, 13], many):
+        one = synth.make_pair(seed, s)
+        for k in ("ref", "curr"):
+            assert np.array_equal(got[k][0], one[k][0]) and np.array_equal(got[k][1], one[k][1])
+        assert np.array_equal(got["T_ref_curr"], one["T_ref_curr"])
