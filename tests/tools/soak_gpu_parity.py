@@ -14,7 +14,8 @@ from revo_amd.settings import (ImgPyramidSettings, PLANE_GRAY, PLANE_DEPTH, PLAN
                                PLANE_EDGES3D, PLANE_DT)
 
 SIZES = [(640, 480, 4, (20, 10, 5, 0, 0, 0)), (320, 240, 3, (10, 5, 0, 0, 0, 0)), (640, 480, 3, (20, 10, 5, 0, 0, 0)),
-         (256, 192, 4, (8, 4, 0, 0, 0, 0)), (448, 336, 3, (16, 8, 4, 0, 0, 0)), (1280, 960, 5, (20, 10, 5, 0, 0, 0))]
+         (256, 192, 4, (8, 4, 0, 0, 0, 0)), (448, 336, 3, (16, 8, 4, 0, 0, 0)), (1280, 960, 5, (20, 10, 5, 0, 0, 0)),
+         (1280, 1024, 3, (20, 10, 5, 0, 0, 0)), (1920, 1080, 4, (20, 10, 5, 0, 0, 0))]  # round 4: beyond one workgroup's LDS / 1024 rows
 
 
 def scene(rng, w, h, kind):

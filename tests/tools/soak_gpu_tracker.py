@@ -24,7 +24,7 @@ def main():
     ot = ro.Tracker(s, OptimizerSettings(), TrackerSettings())
     drot, dtr, ev_same, worst = [], [], 0, []
     for b0 in range(0, n, 32):
-        pairs = [synth.make_pair(seed0 + b0 + i, s) for i in range(32)]
+        pairs = synth.make_pairs(range(seed0 + b0, seed0 + b0 + 32), s)  # rendered on several host cores
         bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).cuda()
         dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).cuda()
         d_res = torch.zeros(32 * 96, dtype=torch.uint8, device="cuda")
