@@ -1273,11 +1273,14 @@ __global__ void __launch_bounds__(HO_THREADS) k_hyst_out(PyrGeom g, FramePlanes 
 }
 
 // a7: fillInEdges (imgpyramidrgbd.cpp:111-145, gate 188-195).  Level l reads
-// the already-filled level l-1, so one 1024-thread block per frame walks the
-// levels in order.
-__global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
+// the already-filled level l-1.  only_level = 0: one 1024-thread block per frame walks the
+// levels in order (640x480: the gate rarely opens and the launch costs 5 us).  only_level = l > 0: that level alone,
+// gridDim.x workgroups per frame share its pixels (large images: one block per frame took 205 us of a 1.19 ms build at
+// 1280x960, where the bench frames do open the gate; the launcher then enqueues the levels one after the other).
+__global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl, int only_level) {
   const int f = g.frame0 + blockIdx.z;
-  for (int l = 1; l < g.n_levels; ++l) {
+  const int la = only_level ? only_level : 1, lb = only_level ? only_level + 1 : g.n_levels;
+  for (int l = la; l < lb; ++l) {
     const LevelGeom lv = g.lv[l], lf = g.lv[l - 1];
     if (!(g.use_edge_hist && lv.patch > 0 && lf.patch > 0)) continue;
     const float frac = (float)pl.hist_nz[f * REVO_L + l] / (float)(lv.hist_w * lv.hist_h);
@@ -1288,7 +1291,7 @@ __global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl) {
       const double thr = g.fill_thr[l];
       // finer pixel (yy,xx) odd,odd <-> coarse pixel (yy/2, xx/2)
       const int cw = lf.w / 2, ch = lf.h / 2;
-      for (int i = threadIdx.x; i < cw * ch; i += 1024) {
+      for (int i = blockIdx.x * 1024 + threadIdx.x; i < cw * ch; i += gridDim.x * 1024) {
         const int y = i / cw, x = i % cw;
         const int yy = 2 * y + 1, xx = 2 * x + 1;
         const int ty = yy / lf.patch, tx = xx / lf.patch;
@@ -2093,7 +2096,16 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
   bool any = false;
   for (int l = 1; l < g.n_levels; ++l) any = any || g.lv[l].has_orig;
-  if (any) hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p);
+  if (!any) return;
+  if (g.lv[0].npix <= 640 * 480) {  // one block per frame, all levels: 5 us, one launch
+    hipLaunchKernelGGL(k_fill, dim3(1, 1, B), dim3(1024), 0, s, g, p, 0);
+    return;
+  }
+  for (int l = 1; l < g.n_levels; ++l) {  // large images: a launch per level, its pixels shared by up to 64 workgroups per frame
+    if (!g.lv[l].has_orig) continue;
+    const int n = (g.lv[l - 1].w / 2) * (g.lv[l - 1].h / 2);
+    hipLaunchKernelGGL(k_fill, dim3(std::min(64, (n + 1023) / 1024), 1, B), dim3(1024), 0, s, g, p, l);
+  }
 }
 
 // the hot path's edge list: tile-ordered, for the tracker (the reference-ordered list is launch_compact, on demand)
