@@ -257,7 +257,11 @@ def make_pairs(seeds, settings, workers=None):
         except AttributeError:
             workers = os.cpu_count() or 1
         workers = max(1, min(16, workers, len(jobs)))
-    if workers <= 1:
+    import sys
+    main = sys.modules.get("__main__")
+    if workers <= 1 or not os.path.isfile(getattr(main, "__file__", None) or ""):
+        # (spawned workers re-import __main__: a script fed through stdin or `python -c` has no file to import and the pool
+        # would wait for ever -- render serially there)
         return [_pair_job(j) for j in jobs]
     with mp.get_context("spawn").Pool(workers) as pool:
         return pool.map(_pair_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
