@@ -142,6 +142,31 @@ def test_edt_exact_vs_scipy_and_bruteforce():
     assert np.all(ro.edt(np.zeros((6, 7), np.uint8)) == np.sqrt(np.float32(1e15)))
 
 
+def test_edt_and_canny_at_the_large_sizes():
+    """Round 4 lifted the device's geometry limits to 1920 x 1080 / 1280 x 1024 and checks them against this oracle: the oracle
+    itself against independent answers there -- the exact EDT against scipy's (far edges: squared distances up to ~2e6, still
+    exact in float), Canny's hysteresis against connected-component labelling of the candidates."""
+    r = np.random.default_rng(11)
+    for h, w in ((1080, 1920), (1024, 1280)):
+        e = np.zeros((h, w), np.uint8)
+        ys, xs = r.integers(0, h, 40), r.integers(0, w, 40)  # a few edges: most pixels are hundreds of pixels from the nearest one
+        e[ys, xs] = 255
+        e[h // 2, : w // 3] = 255
+        dt = ro.edt(e)
+        ref = ndi.distance_transform_edt(e == 0)
+        assert np.array_equal(dt, ref.astype(np.float32))
+        assert dt.max() > 250
+    g = ndi.gaussian_filter(r.uniform(0, 255, (1080, 1920)), 2.5)
+    gray = np.clip((g - g.mean()) * 10 + 128, 0, 255).astype(np.uint8)
+    C = ro.canny(gray, 100, 100) > 0     # all candidates (every NMS survivor above the low threshold is "strong")
+    S = ro.canny(gray, 150, 150) > 0     # the strong ones
+    E = ro.canny(gray, 150, 100) > 0
+    lab, _ = ndi.label(C, structure=np.ones((3, 3), bool))
+    keep = np.unique(lab[S])
+    assert S.sum() > 1000 and (C & ~S).sum() > 1000
+    assert np.array_equal(E, np.isin(lab, keep[keep > 0]))
+
+
 def test_grad_table_layout():
     dt = rng.uniform(0, 20, (9, 11)).astype(np.float32)
     t = ro.grad_table(dt)
