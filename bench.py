@@ -398,7 +398,7 @@ def main():
 
     def make_step(nb, tracks, builds, edts, outs, main):
         """One pipeline shape: `nb` batches in rotation, tracker grids alternating over `tracks`, builds over `builds`,
-        the deferred keyframe EDTs on `edts` (empty: on the tracker's stream).  main: the timed headline loop (records of
+        what a build leaves to its first consumer (edge lists + keyframe EDT, REVO_DEFER) on `edts` (empty: on the tracker's stream).  main: the timed headline loop (records of
         every step kept, k_track timed live, the collective in the loop)."""
         ev_built = [torch.cuda.Event() for _ in range(nb)]
         ev_edt = [torch.cuda.Event() for _ in range(nb)]
@@ -438,9 +438,10 @@ def main():
                 bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_tr.cuda_stream, borrow_depth=True)
                 bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
             ev_tracked[k].record(s_tr)
-            if main and use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1), on its own stream:
-                # nothing on the device waits for it (the host reads the gathered records after the run), so it is off the
-                # tracker stream's chain; it is inside the timed region all the same (synchronize + barrier below)
+            if main and use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1).  Default: on the
+                # tracker's stream, right behind the grid whose records it gathers (a fifth active stream would end up behind
+                # another stream's kernels in one of HIP's four hardware queues: DESIGN 3.0 item 5); --coll-own-stream: on a
+                # stream of its own behind the grid's event.  Inside the timed region either way (synchronize + barrier below).
                 s_c = s_tr if a.coll_on_track else s_coll
                 if not a.coll_on_track:
                     s_c.wait_event(ev_tracked[k])
