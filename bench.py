@@ -28,6 +28,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def csrc_sha16():
+    """Identity of the kernel sources a measurement was taken with: sha256 over revo_amd/csrc/*.hip|*.h (names + contents).
+    profiles/pmc_summary.py stamps it into the PMC summary; a summary taken with other sources is not quoted as `traffic`."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "revo_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes
     expose 256 hardware threads but grant 16 CPUs: cpu.max = "1600000 100000")."""
@@ -60,6 +73,19 @@ def cpu_info():
         pass
     allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     return model, allowed
+
+
+def baseline_config(w, h, levels, pairs, world):
+    """Which BASELINE.json configuration a run IS, by geometry (VERDICT r04 #10), not by world size alone."""
+    if (w, h, levels) == (640, 480, 4):
+        if world == 1 and pairs == 32:
+            return "BASELINE configs[2]: synthetic 640x480 stream, 1 MI355X, batch = 32 frame-pairs"
+        if world == 8 and pairs == 32:
+            return "BASELINE configs[4]: batch = 256 frame-pairs sharded over 8 MI355X, RCCL gather"
+        return "BASELINE configs[2]/[4] geometry with %d pairs per GPU on %d GPU(s)" % (pairs, world)
+    if (w, h, levels) == (1280, 960, 5):
+        return "BASELINE configs[3]: synthetic 1280x960, 5-level pyramid, 1 MI355X" + ("" if world == 1 else " (here on %d GPUs)" % world)
+    return "not a BASELINE configuration: %dx%d, %d levels" % (w, h, levels)
 
 
 def render_pair(args):
@@ -135,8 +161,12 @@ def run_tum_stream(a, device):
 
 def dry_run_cpu(a, world, rank, json_fd):
     """The rank plumbing of this file without a GPU (gloo): spawn/rendezvous (done by the caller), static shard, one
-    96-byte record per pair from a stubbed step, the all_gather, max-over-ranks timing, ONE JSON line from rank 0.
-    No measurement: value is null and the line says dry_run."""
+    96-byte record per pair from a stubbed step, the gather schedule (--gather-every) with the STREAM semantics of the real
+    loop -- the collective of a window is issued asynchronously behind the window's last step and is waited for only when
+    its tracker stream is used again, two steps later --, max-over-ranks timing, ONE JSON line from rank 0.
+    No measurement: value is null and the line says dry_run.  --dry-run-step-ms makes the stubbed step take time and
+    --dry-run-delay-rank/-ms make one rank late in one step: `ms_loop_per_rank` (every rank's clock around its own step
+    loop, before the final drain) then shows whether the others were stalled behind it."""
     import torch
     import torch.distributed as dist
     from revo_amd import parallel
@@ -144,37 +174,84 @@ def dry_run_cpu(a, world, rank, json_fd):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(parallel.free_port()))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    every = a.gather_every or parallel.gather_every_default(world)
     seeds = parallel.shard_pairs(world * a.pairs, rank, world)
-    rec = np.zeros((a.pairs, parallel.RECORD_BYTES // 4), np.float32)
-    rec[:, 0] = seeds   # what a tracker would write: here the pair's global index ...
-    rec[:, 9] = rank    # ... and the rank that "tracked" it
-    local = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
-    out = torch.empty(world * local.numel(), dtype=torch.uint8)
-    for _ in range(a.warmup):
-        parallel.gather_records(local, world, out=out)
+    n_slots = a.warmup + a.steps
+    nrec = parallel.RECORD_BYTES // 4
+    rec_all = np.zeros((n_slots, a.pairs, nrec), np.float32)  # one record slot per step, like the real loop
+    local_all = torch.from_numpy(rec_all.view(np.uint8).reshape(n_slots, -1))
+    outs = {}
+    pending = []  # (stream index, work handle, out tensor, first step, n steps)
+    checked = [0]
+
+    def check(out, first, n):
+        g = out.numpy().view(np.float32).reshape(world, n, a.pairs, nrec)
+        for r in range(world):
+            for k in range(n):
+                if not (np.array_equal(g[r, k, :, 0], np.arange(r * a.pairs, (r + 1) * a.pairs, dtype=np.float32))
+                        and np.all(g[r, k, :, 9] == r) and np.all(g[r, k, :, 10] == first + k)):
+                    raise SystemExit("bench --dry-run-cpu: the gather did not return every rank's records of steps %d..%d in rank order"
+                                     % (first, first + n - 1))
+        checked[0] += n
+
+    def wait_stream(si):
+        for item in [x for x in pending if x[0] == si or si < 0]:
+            item[1].wait()
+            check(item[2], item[3], item[4])
+            pending.remove(item)
+
+    def issue(first, n, si):
+        src = local_all[first:first + n].reshape(-1)
+        out = outs.setdefault((n, si), torch.empty(world * src.numel(), dtype=torch.uint8))
+        pending.append((si, dist.all_gather_into_tensor(out, src, async_op=True), out, first, n))
+
+    def step(t, start):
+        si = t % 2                       # the tracker stream of step t
+        wait_stream(si)                  # its grid sits behind whatever was enqueued on that stream before
+        if a.dry_run_step_ms > 0:
+            time.sleep(a.dry_run_step_ms * 1e-3)
+        if rank == a.dry_run_delay_rank and t == a.warmup + 2 and a.dry_run_delay_ms > 0:
+            time.sleep(a.dry_run_delay_ms * 1e-3)
+        rec_all[t, :, 0] = seeds         # what a tracker would write: the pair's global index ...
+        rec_all[t, :, 9] = rank          # ... the rank that "tracked" it ...
+        rec_all[t, :, 10] = t            # ... and the step
+        win = parallel.gather_window(t, every, start)
+        if win:
+            issue(win[0], win[1], si)
+
+    def phase(start, end):
+        for t in range(start, end):
+            step(t, start)
+        loop = time.perf_counter()
+        tail = parallel.gather_tail(end, every, start)  # what the last window did not cover travels in one final collective
+        if tail:
+            issue(tail[0], tail[1], (end - 1) % 2)
+        wait_stream(-1)
+        return loop
+
+    phase(0, a.warmup)
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        got = parallel.gather_records(local, world, out=out)
-    dist.barrier()
+    loop_s = phase(a.warmup, n_slots) - t0  # this rank's own loop: nobody has been waited for beyond the stream order
     mine_s = time.perf_counter() - t0
+    dist.barrier()
     per_rank = parallel.gather_floats(mine_s, world)
-    elapsed = parallel.max_over_ranks(mine_s, world)
+    loop_per_rank = parallel.gather_floats(loop_s, world)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, world)
     seen, wsz = parallel.ranks_seen(world)
     if len(set(seen)) != world or wsz != world:
         raise SystemExit("bench --dry-run-cpu: the process group saw ranks %s (size %d) but WORLD_SIZE is %d" % (seen, wsz, world))
-    g = got.numpy().view(np.float32).reshape(world * a.pairs, -1)
-    if not (np.array_equal(g[:, 0], np.arange(world * a.pairs, dtype=np.float32))
-            and np.array_equal(g[:, 9], np.repeat(np.arange(world, dtype=np.float32), a.pairs))):
-        raise SystemExit("bench --dry-run-cpu: the gather did not return every rank's records in rank order")
     if rank == 0:
         line = {"metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference", "value": None, "unit": "frames/s",
                 "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
                 "ms_per_step_per_rank": [x / max(1, a.steps) * 1e3 for x in per_rank],
+                "ms_loop_per_rank": [x * 1e3 for x in loop_per_rank],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none (stubbed step)",
                 "config": {"workload": "orchestration dry run on CPU (gloo): no kernels", "pairs_per_gpu": a.pairs,
                            "global_pairs": world * a.pairs},
-                "collective": {"backend": "gloo", "executed_every_step": True, "bytes_per_rank": a.pairs * parallel.RECORD_BYTES,
+                "collective": {"backend": "gloo", "executed_every_step": every == 1, "steps_per_collective": every,
+                               "steps_gathered_and_checked": checked[0],
+                               "bytes_per_rank": a.pairs * parallel.RECORD_BYTES * every,
                                "ranks_seen": seen, "world_size": wsz}}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
@@ -227,6 +304,17 @@ def main():
                     help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
                          "than the 256 MB Infinity Cache, so 'resident in HBM' cannot mean 'resident in the last-level cache')")
     ap.add_argument("--single-stream-runs", type=int, default=5, help="full-length runs of the sequential stream (median reported)")
+    ap.add_argument("--shape", default="lib", choices=["lib", "bench"],
+                    help="lib (default): the timed loop drives the library's pipeline handle (revo_pipeline_*: it owns the four "
+                         "streams, the batches and the event wiring); bench: the same choreography built here from the batch entry "
+                         "points (round 4's loop, kept for A/B experiments with --track-streams / --edt-streams / --build-streams)")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="steps per RCCL all_gather (the records of that many steps travel in one collective, in the after-grid slot "
+                         "of the last of them); 0 = automatic: 1 at N = 1, 2 at N > 1 (ranks then synchronise every second step "
+                         "only: a rank may lag a full step without stalling the others' tracker streams)")
+    ap.add_argument("--dry-run-delay-rank", type=int, default=-1, help="--dry-run-cpu: this rank sleeps --dry-run-delay-ms in one step")
+    ap.add_argument("--dry-run-delay-ms", type=float, default=0.0)
+    ap.add_argument("--dry-run-step-ms", type=float, default=0.0, help="--dry-run-cpu: duration of the stubbed step")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="orchestration check without a GPU: the rank plumbing of this file (spawn, rendezvous, shard, records, "
                          "gather, max-over-ranks, one JSON line from rank 0) on the gloo backend with a stubbed step; the line "
@@ -358,13 +446,12 @@ def main():
             group_error = "%s: %s" % (type(e).__name__, e)
     use_group = dist.is_initialized()
 
-    # Two batches, two streams: the pyramid build of step k+1 (streaming, all CUs) overlaps the
-    # tracker of step k (192 latency-bound workgroups).  Trackers serialise on one stream,
-    # builds on the other; events hand each batch back and forth.
+    # The pipelined step: `nbuf` batches in rotation over four streams -- build(t+3) | edge lists + keyframe EDT(t+2) | the
+    # tracker grids of steps t+1 and t on two alternating streams (the library's resident gate keeps two grids in flight).
+    # --shape lib (default): the library's pipeline handle owns all of it (revo_pipeline_*); --shape bench:
+    # the same choreography built here from the batch entry points (round 4's loop, for A/B experiments).
+    use_lib = a.shape == "lib"
     nbuf = 1 if a.no_overlap else max(2, a.buffers)
-    nbuf_alloc = max(2, nbuf)  # (the two-batch side measurement below needs two)
-    bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf_alloc)]
-    bt = bts[0]
     d_bgrs = [torch.from_numpy(b).to(dev) for b in bgrs]
     d_deps = [torch.from_numpy(d).to(dev) for d in deps]
     d_bgr, d_dep = d_bgrs[0], d_deps[0]
@@ -374,110 +461,181 @@ def main():
     d_ress = [d_res_all[i * a.pairs * 96:(i + 1) * a.pairs * 96] for i in range(max(1, n_slots))]
     d_res = d_ress[0]
     d_res_side = torch.zeros(a.pairs * 96, dtype=torch.uint8, device=dev)  # side measurements write here
-    s_track = torch.cuda.Stream(device=dev, priority=a.track_priority)
-    # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
-    # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
-    n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
-    s_tracks = [s_track] + [torch.cuda.Stream(device=dev, priority=a.track_priority) for _ in range(n_tr - 1)]
-    s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective
-    s_build = torch.cuda.Stream(device=dev, priority=a.build_priority)
-    # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
-    s_builds = [s_build] + [torch.cuda.Stream(device=dev, priority=a.build_priority) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
-    s_edts = [torch.cuda.Stream(device=dev) for _ in range(max(0, a.edt_streams) if nbuf >= 2 else 0)]
-    torch.cuda.set_stream(s_track)
-    stream = s_track.cuda_stream
-    assert stream != 0 and s_build.cuda_stream != 0
+    every = max(1, a.gather_every or parallel.gather_every_default(world))  # steps per collective
     # the timing events cost ~1.5 % of the step when every launch carries a pair (two marker packets in front of / behind
     # each tracker on its stream): every 4th launch of the timed region is timed (every launch when there are few)
     TIME_EVERY = int(os.environ.get('REVO_BENCH_TIME_EVERY', '4' if a.steps >= 16 else '1'))
-    timing, track_events = [False], []  # the dominant kernel is timed live in the timed steps (roofline)
-    gathered = [None]  # every rank's 96-byte pair records, in rank order (the path's only collective)
-    d_all = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev) if use_group else None
-    # (--coll-on-track: gathers of consecutive steps run on different streams; each stream gathers into its own buffer)
-    d_alls = [torch.zeros_like(d_all) for _ in s_tracks] if (use_group and a.coll_on_track) else None
+    gathered = [None, None]  # the last collective: (tensor with every rank's records in rank order, (first step, n steps))
+    d_alls = {}              # (steps in the window, stream) -> the collective's output buffer
+    ev_grid = [torch.cuda.Event() for _ in range(8)]  # grid of step t done (cross-stream order of a multi-step window)
+    ext_streams = {}
 
-    def make_step(nb, tracks, builds, edts, outs, main):
-        """One pipeline shape: `nb` batches in rotation, tracker grids alternating over `tracks`, builds over `builds`,
-        what a build leaves to its first consumer (edge lists + keyframe EDT, REVO_DEFER) on `edts` (empty: on the tracker's stream).  main: the timed headline loop (records of
-        every step kept, k_track timed live, the collective in the loop)."""
-        ev_built = [torch.cuda.Event() for _ in range(nb)]
-        ev_edt = [torch.cuda.Event() for _ in range(nb)]
-        ev_tracked = [torch.cuda.Event() for _ in range(nb)]
+    def ext(handle):
+        if handle not in ext_streams:
+            ext_streams[handle] = torch.cuda.ExternalStream(handle, device=dev)
+        return ext_streams[handle]
+
+    def after_grid(t, s_tr, start):
+        """The path's only collective: 96 B x pairs (x steps of the window) per rank, RCCL (over xGMI at N > 1), enqueued on the
+        tracker's stream right behind the grid of the window's last step -- the after-grid slot of the pipeline (a fifth active
+        stream would end up behind another stream's kernels in one of HIP's hardware queues: DESIGN 3.0).  Inside the timed
+        region (synchronize + barrier below)."""
+        if not use_group:
+            return
+        ev_grid[t % len(ev_grid)].record(s_tr)
+        win = parallel.gather_window(t, every, start)
+        if win:
+            issue_gather(win, s_tr)
+
+    def issue_gather(win, s_tr):
+        first, n = win
+        for u in range(first, first + n - 1):  # the window's earlier grids ran on the other tracker stream
+            s_tr.wait_event(ev_grid[u % len(ev_grid)])
+        src = d_res_all[first * a.pairs * 96:(first + n) * a.pairs * 96]
+        key = (n, s_tr.cuda_stream)
+        if key not in d_alls:
+            d_alls[key] = torch.zeros(world * n * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(s_tr):
+            gathered[0] = parallel.gather_records(src, world, out=d_alls[key])
+        gathered[1] = win
+
+    pipe = None
+    track_events = []
+    timing = [False]
+    if use_lib:
+        pipe = api.Pipeline(cam, a.pairs, depth=nbuf)
+        pipe_info = pipe.info()
         counter = [0]
+        phase_start = [0]
 
         def step():
             t = counter[0]
-            k = t % nb
-            d_out = outs[t % len(outs)]
-            j_in = t % nin                      # the input batches rotate: step t reads input t mod nin
-            s_tr = tracks[t % len(tracks)]
             counter[0] += 1
-            if nb >= 2:
-                s_bld = builds[t % len(builds)]
-                s_bld.wait_event(ev_tracked[k])          # batch k free again (its previous tracker is done)
-                bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_bld.cuda_stream, borrow_depth=True)
-                ev_built[k].record(s_bld)
-                if edts:  # the keyframes' EDT on its own stream: off the build stream's chain AND off the tracker's
-                    s_e = edts[t % len(edts)]
-                    s_e.wait_event(ev_built[k])
-                    bts[k].prepare(stream=s_e.cuda_stream)
-                    ev_edt[k].record(s_e)
-                    s_tr.wait_event(ev_edt[k])
-                else:
-                    s_tr.wait_event(ev_built[k])
-                if main and timing[0] and (counter[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
-                    e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    bts[k].prepare(stream=s_tr.cuda_stream)  # the keyframes' EDT the build left to this stream: not k_track
-                    e_a.record(s_tr)
-                    bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-                    e_b.record(s_tr)
-                    track_events.append((e_a, e_b))
-                else:
-                    bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-            else:  # one batch, one stream: nothing overlaps anything
-                bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_tr.cuda_stream, borrow_depth=True)
-                bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-            ev_tracked[k].record(s_tr)
-            if main and use_group:  # the only collective: 96 B x pairs per rank, RCCL (over xGMI at N > 1).  Default: on the
-                # tracker's stream, right behind the grid whose records it gathers (a fifth active stream would end up behind
-                # another stream's kernels in one of HIP's four hardware queues: DESIGN 3.0 item 5); --coll-own-stream: on a
-                # stream of its own behind the grid's event.  Inside the timed region either way (synchronize + barrier below).
-                s_c = s_tr if a.coll_on_track else s_coll
-                if not a.coll_on_track:
-                    s_c.wait_event(ev_tracked[k])
-                with torch.cuda.stream(s_c):
-                    gathered[0] = parallel.gather_records(d_out, world, out=d_alls[t % len(tracks)] if a.coll_on_track else d_all)
-        return step, counter
+            ticket, sh = pipe.submit(d_bgrs[t % nin].data_ptr(), d_deps[t % nin].data_ptr(), d_ress[t % len(d_ress)].data_ptr())
+            after_grid(t, ext(sh), phase_start[0])
+        s_track = ext(pipe_info["streams"][0])
+        s_tracks = [ext(h) for h in sorted(set(pipe_info["streams"][:2]), key=pipe_info["streams"].index)]
+        s_build = ext(pipe_info["streams"][2])
+        s_edts = [ext(pipe_info["streams"][3])] if pipe_info["streams"][3] != pipe_info["streams"][2] else []
+        bts = []
+    else:
+        pipe_info = None
+        nbuf_alloc = max(2, nbuf)
+        bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf_alloc)]
+        s_track = torch.cuda.Stream(device=dev, priority=a.track_priority)
+        # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
+        # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
+        n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
+        s_tracks = [s_track] + [torch.cuda.Stream(device=dev, priority=a.track_priority) for _ in range(n_tr - 1)]
+        s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective with --coll-own-stream
+        s_build = torch.cuda.Stream(device=dev, priority=a.build_priority)
+        # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
+        s_builds = [s_build] + [torch.cuda.Stream(device=dev, priority=a.build_priority) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
+        s_edts = [torch.cuda.Stream(device=dev) for _ in range(max(0, a.edt_streams) if nbuf >= 2 else 0)]
+        phase_start = [0]
 
-    step, counter = make_step(nbuf, s_tracks, s_builds, s_edts, d_ress, True)
+        def make_step(nb, tracks, builds, edts, outs, main):
+            """One pipeline shape: `nb` batches in rotation, tracker grids alternating over `tracks`, builds over `builds`,
+            what a build leaves to its first consumer (edge lists + keyframe EDT, REVO_DEFER) on `edts` (empty: on the tracker's
+            stream).  main: the timed headline loop (records of every step kept, k_track timed live, the collective in the loop)."""
+            ev_built = [torch.cuda.Event() for _ in range(nb)]
+            ev_edt = [torch.cuda.Event() for _ in range(nb)]
+            ev_tracked = [torch.cuda.Event() for _ in range(nb)]
+            cnt = [0]
+
+            def step():
+                t = cnt[0]
+                k = t % nb
+                d_out = outs[t % len(outs)]
+                j_in = t % nin                      # the input batches rotate: step t reads input t mod nin
+                s_tr = tracks[t % len(tracks)]
+                cnt[0] += 1
+                if nb >= 2:
+                    s_bld = builds[t % len(builds)]
+                    s_bld.wait_event(ev_tracked[k])          # batch k free again (its previous tracker is done)
+                    bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_bld.cuda_stream, borrow_depth=True)
+                    ev_built[k].record(s_bld)
+                    if edts:  # the keyframes' EDT on its own stream: off the build stream's chain AND off the tracker's
+                        s_e = edts[t % len(edts)]
+                        s_e.wait_event(ev_built[k])
+                        bts[k].prepare(stream=s_e.cuda_stream)
+                        ev_edt[k].record(s_e)
+                        s_tr.wait_event(ev_edt[k])
+                    else:
+                        s_tr.wait_event(ev_built[k])
+                    if main and timing[0] and (cnt[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
+                        e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        bts[k].prepare(stream=s_tr.cuda_stream)  # the keyframes' EDT the build left to this stream: not k_track
+                        e_a.record(s_tr)
+                        bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
+                        e_b.record(s_tr)
+                        track_events.append((e_a, e_b))
+                    else:
+                        bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
+                else:  # one batch, one stream: nothing overlaps anything
+                    bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_tr.cuda_stream, borrow_depth=True)
+                    bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
+                ev_tracked[k].record(s_tr)
+                if main:
+                    if a.coll_on_track:
+                        after_grid(t, s_tr, phase_start[0])
+                    elif use_group:  # --coll-own-stream: on a stream of its own behind the grid's event (every step)
+                        s_coll.wait_event(ev_tracked[k])
+                        with torch.cuda.stream(s_coll):
+                            gathered[0] = parallel.gather_records(d_out, world, out=d_alls.setdefault((1, 0), torch.zeros(world * a.pairs * 96, dtype=torch.uint8, device=dev)))
+                        gathered[1] = (t, 1)
+            return step, cnt
+
+        step, counter = make_step(nbuf, s_tracks, s_builds, s_edts, d_ress, True)
+    torch.cuda.set_stream(s_track)
+    stream = s_track.cuda_stream
+    assert stream != 0 and s_build.cuda_stream != 0
+
+    def close_phase(end):
+        """what the last window of a phase did not cover travels in one final collective"""
+        tail = parallel.gather_tail(end, every, phase_start[0])
+        if use_group and tail and (use_lib or a.coll_on_track):
+            issue_gather(tail, s_tracks[(end - 1) % len(s_tracks)])
 
     for _ in range(a.warmup):
         step()
+    close_phase(a.warmup)
     torch.cuda.synchronize()
     if use_group:
         dist.barrier()
     torch.cuda.synchronize()
     timing[0] = True
+    phase_start[0] = a.warmup
+    if pipe is not None:
+        pipe.time_tracker(TIME_EVERY)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    close_phase(n_slots)
     torch.cuda.synchronize()
+    mine_s = time.perf_counter() - t0  # this rank's own clock: its streams have drained, nobody has been waited for at a barrier yet
     if use_group:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing[0] = False
-    ms_per_rank = [x / a.steps * 1e3 for x in parallel.gather_floats(elapsed, world, device=dev)] if use_group else [elapsed / a.steps * 1e3]
+    ms_per_rank = [x / a.steps * 1e3 for x in parallel.gather_floats(mine_s, world, device=dev)] if use_group else [mine_s / a.steps * 1e3]
     elapsed = parallel.max_over_ranks(elapsed, world, device=dev)
     d_res = d_ress[(counter[0] - 1) % len(d_ress)]
-    bt = bts[(counter[0] - 1) % nbuf]
-    if use_group:  # the gathered buffer of the last step holds this rank's records at its rank offset
-        got = gathered[0]
-        if got is None or got.numel() != world * a.pairs * parallel.RECORD_BYTES:
+    if use_group:  # the gathered buffer of the last collective holds this rank's records of its window at its rank offset
+        got, win = gathered
+        if got is None or got.numel() != world * win[1] * a.pairs * parallel.RECORD_BYTES:
             raise SystemExit("bench: gathered record buffer has the wrong size")
-        mine = got[rank * a.pairs * 96:(rank + 1) * a.pairs * 96]
-        if not torch.equal(mine, d_res):
+        wb = win[1] * a.pairs * 96
+        mine = got[rank * wb:(rank + 1) * wb]
+        if not torch.equal(mine, d_res_all[win[0] * a.pairs * 96:(win[0] + win[1]) * a.pairs * 96]):
             raise SystemExit("bench: the RCCL gather did not return this rank's records")
+    if pipe is not None:
+        pipe.drain()
+        ms_live, n_live = pipe.tracker_ms()
+        pipe.time_tracker(0)
+    # one batch for the measurements outside the timed region (stage split, k_track alone, point counts)
+    bt = api.BatchTracker(cam, a.pairs) if use_lib else bts[(counter[0] - 1) % nbuf]
 
     # ---- correctness of what was timed (never skipped work): the flags of EVERY step, poses vs ground truth
     all_res = api.results_from_buffer(d_res_all.cpu().numpy().tobytes(), n_slots * a.pairs)
@@ -498,7 +656,12 @@ def main():
     # ---- roofline of the dominant kernel (k_track): HIP events on its stream around every launch of the
     # timed region (next to the other stream's build kernels); `kernel_ms_alone` re-times it with nothing else
     # running (revo_batch_time_tracker)
-    ms_track = (float(np.mean([ea.elapsed_time(eb) for ea, eb in track_events])) if track_events else None)
+    if use_lib:  # the pipeline handle's own event pairs (revo_pipeline_time_tracker), harvested after the drain
+        ms_track = float(ms_live) if n_live else None
+        n_timed = n_live
+    else:
+        ms_track = (float(np.mean([ea.elapsed_time(eb) for ea, eb in track_events])) if track_events else None)
+        n_timed = len(track_events)
     # algorithmic bytes per launch, SURVEY 8(d): B_trk = sum_l E_l*N_l*(16 + 4*16) + init check 2*N_c*(16+4) -- the mean
     # over the input batches of the rotation (every one is rebuilt and tracked once more here, outside the timed
     # region, to read its point counts; `kernel_ms_alone` averages over the same inputs)
@@ -547,7 +710,15 @@ def main():
     # (build -> keyframes -> tracker on one stream) and with TWO batches (the build of step k+1 next to the tracker of step
     # k, one tracker stream).  Same kernels, same inputs, no collective; 3 warm-up + 20 timed steps each, this rank only.
     def side_rate(nb):
-        st, _ = make_step(nb, [s_track], [s_build], [], [d_res_side], False)
+        if use_lib:
+            sp = api.Pipeline(cam, a.pairs, depth=nb)
+            cnt = [0]
+
+            def st():
+                sp.submit(d_bgrs[cnt[0] % nin].data_ptr(), d_deps[cnt[0] % nin].data_ptr(), d_res_side.data_ptr())
+                cnt[0] += 1
+        else:
+            st, _ = make_step(nb, [s_track], [s_build], [], [d_res_side], False)
         for _ in range(3):
             st()
         torch.cuda.synchronize()
@@ -555,24 +726,70 @@ def main():
         for _ in range(20):
             st()
         torch.cuda.synchronize()
-        return a.pairs * 20 / (time.perf_counter() - t0s)
+        rate = a.pairs * 20 / (time.perf_counter() - t0s)
+        if use_lib:
+            sp.close()
+        return rate
     value_single = side_rate(1) if not a.no_overlap else a.pairs * a.steps / elapsed
     value_two = side_rate(2) if not a.no_overlap else None
 
-    # HBM traffic of k_track per launch from the PMC passes recorded under profiles/ (same workload;
-    # counters cannot be collected inside this process)
-    traffic, traffic_src = None, None
-    for pmc_name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):  # the newest committed pass of this workload
+    # HBM traffic of k_track per launch from the PMC passes recorded under profiles/ (same workload; counters cannot be
+    # collected inside this process).  The summary carries the hash of the kernel sources it was taken with: a summary of other
+    # sources is NOT quoted (the constant must not go stale silently).
+    traffic, traffic_src, traffic_commit = None, None, None
+    src_now = csrc_sha16()
+    for pmc_name in ("r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest committed pass of this workload
         pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_file) and a.pairs == 32 and a.width == 640 and a.levels == 4:
             try:
                 pmc = json.load(open(pmc_file))
+                if pmc.get("csrc_sha16") != src_now:
+                    traffic_src = ("none: profiles/%s was taken with kernel sources %s, this run has %s -- re-run the PMC passes "
+                                   "(profiles/README.md)" % (pmc_name, pmc.get("csrc_sha16", "(unstamped)"), src_now))
+                    continue
                 traffic = float(next(v for k, v in pmc.items() if k.startswith("k_track"))["hbm_bytes_per_launch"])
+                traffic_commit = pmc.get("commit")
                 traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of the default pipelined "
-                               "command; a committed measurement of the builder's, not taken inside this run)" % pmc_name)
+                               "command; a committed measurement of the builder's, not taken inside this run; same kernel "
+                               "sources: csrc_sha16 %s)" % (pmc_name, src_now))
                 break
             except Exception:
                 traffic = None
+
+    # ---- per-kernel roofline table of the build (VERDICT r04 #6b): every kernel alone (HIP events between the launches,
+    # revo_batch_profile_build), its algorithmic bytes per launch (what the kernel must read and write once,
+    # 2*pairs frames per launch, `pairs` keyframes for the EDT) and the fraction of the HBM peak that makes
+    P = [(a.width >> l) * (a.height >> l) for l in range(a.levels)]
+    SP = float(sum(P))
+    nframes = 2 * a.pairs
+    has_orig = [l >= 1 and hist[l] > 0 and hist[l - 1] > 0 for l in range(a.levels)]
+    P_orig = float(sum(P[l] for l in range(a.levels) if has_orig[l]))
+    SN = float(npts.sum(1).mean())  # edge points per frame, all levels (the current frames of the batches)
+    kbytes = {"k_gray_depth": nframes * 4.0 * P[0],
+              "k_canny_nms4": nframes * (SP + SP / 4),
+              "hysteresis": nframes * (SP / 4 + SP + P_orig + SP / 8),
+              "k_fill": None,
+              "k_tile_count": nframes * (SP / 8 + SP / 8),
+              "k_pts_tiles": nframes * (SP / 8 + SP / 8 + 4 * SN + 16 * SN),
+              "k_edt_cols": a.pairs * (SP / 8 + 2 * SP),
+              "k_edt_rows": a.pairs * (2 * SP + 4 * SP)}
+    for l in range(1, a.levels):
+        kbytes["k_pyrdown[%d]" % l] = nframes * (5.0 * P[l - 1] + 5.0 * P[l] + P[l - 1] / 8)
+    kernels = []
+    try:
+        for name, us in bt.profile_build(d_bgr.data_ptr(), d_dep.data_ptr(), reps=3):
+            kb = kbytes.get(name)
+            kernels.append({"kernel": name, "us_alone": us, "algorithmic_bytes_per_launch": kb,
+                            "frac": (kb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (kb and us > 0) else None})
+    except Exception as e:  # noqa: BLE001 -- a side table must not cost the line
+        kernels = [{"error": "%s: %s" % (type(e).__name__, e)}]
+    kernels.append({"kernel": "k_track", "us_alone": ms_track_alone * 1e3, "us_in_step": ms_track * 1e3,
+                    "algorithmic_bytes_per_launch": b_trk, "frac": b_trk / (ms_track_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_in_step": achieved / HBM_PEAK_GBS})
+    # the whole step against the roofline, SURVEY 8(d): per independent frame-pair 2*B_pyr + B_kf + B_trk
+    b_pyr = 7.0 * P[0] + SP + 4.0 * (SP - P[0]) + SP + P_orig + 16.0 * SN
+    b_kf = SP + 4.0 * SP + 16.0 * SP
+    step_bytes_alg = a.pairs * (2 * b_pyr + b_kf) + b_trk
     # on-box streaming ceiling next to the vendor peak: a 1 GiB device-to-device copy
     copy_gbs = None
     if rank == 0:
@@ -598,9 +815,10 @@ def main():
     if use_group:  # the collective alone (latency-bound: 96 B x pairs per rank)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d_alone = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev)
         e0.record()
         for _ in range(20):
-            parallel.gather_records(d_res, world, out=d_all)
+            parallel.gather_records(d_res, world, out=d_alone)
         e1.record()
         torch.cuda.synchronize()
         gather_us = e0.elapsed_time(e1) * 1e3 / 20
@@ -623,31 +841,43 @@ def main():
         "value_two_batches": value_two * world if value_two else None,
         "value_pairs_resident": {"value": nbuf * a.pairs, "value_two_batches": 2 * a.pairs, "value_single_batch_in_flight": a.pairs},
         "config": {
-            "workload": "synthetic %dx%d RGB-D, %d-level pyramid, %d independent frame-pairs in flight per GPU "
-                        "(BASELINE configs[%d]); per pair: 2 pyramid builds + keyframe (EDT+table) + trackFrames"
-                        % (a.width, a.height, a.levels, a.pairs, 2 if world == 1 else 4),
+            "workload": "synthetic %dx%d RGB-D, %d-level pyramid, %d independent frame-pairs per step and GPU "
+                        "(%s); per pair: 2 pyramid builds + keyframe (EDT+table) + trackFrames"
+                        % (a.width, a.height, a.levels, a.pairs, baseline_config(a.width, a.height, a.levels, a.pairs, world)),
             "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
-            "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair per step" % world,
+            "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair x %d step(s) every %d step(s)" % (world, every, every),
+            "pipeline": ({"owner": "library (revo_pipeline_*)", **{k: v for k, v in pipe_info.items() if k != "streams"}} if use_lib
+                         else {"owner": "bench.py (--shape bench: round 4's loop over the batch entry points)"}),
             "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
                                                         "earlier ones; consecutive tracker grids on %d stream(s), ordered by the library's "
                                                         "resident gate (at most %s in flight)%s" % (nbuf, a.pairs, len(s_tracks), os.environ.get("REVO_TRACK_DEPTH", "2"),
-                                                                                                  "; what the build leaves to its first consumer (REVO_DEFER=%s: 1 = the keyframes' EDT, 2 = + the edge lists, 3 = + hysteresis) on %d stream(s) of its own; the RCCL gather %s" % (os.environ.get("REVO_DEFER", "2"), len(s_edts), "on the tracker's stream, behind the grid" if a.coll_on_track else "on its own stream") if s_edts else "")),
+                                                                                                  "; what the build leaves to its first consumer (REVO_DEFER=%s: 1 = the keyframes' EDT, 2 = + the edge lists, 3 = + hysteresis) on %d stream(s) of its own; the RCCL gather %s" % (os.environ.get("REVO_DEFER", "2"), len(s_edts), "on the tracker's stream, behind the grid" if (use_lib or a.coll_on_track) else "on its own stream") if s_edts else "")),
             "batches_in_rotation": nbuf, "pairs_resident": nbuf * a.pairs,
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": traffic_src,
+            "traffic_source": traffic_src, "traffic_commit": traffic_commit, "csrc_sha16": src_now,
             "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track, "kernel_ms_alone": ms_track_alone,
             "frac_alone": b_trk / (ms_track_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # two tracker grids are in flight (resident gate): a launch lasts longer than the interval at which launches
             # complete; `frac` above is per launch as the rules ask, this is the same bytes over the step interval
             "frac_per_step_interval": b_trk / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
-            "timing": "HIP events on the tracker's stream around %d of the %d launches of the timed region (every %d-th)" % (max(1, len(track_events)), a.steps, TIME_EVERY),
+            "timing": "HIP events on the tracker's stream around %d of the %d launches of the timed region (every %d-th%s)"
+                      % (max(1, n_timed), a.steps, TIME_EVERY, "; recorded by the pipeline handle, revo_pipeline_time_tracker" if use_lib else ""),
             "measured_copy_gbs": copy_gbs,  # on-box device-to-device copy ceiling (read + write bytes), for context
+            # the WHOLE step against the roofline: SURVEY 8(d)'s bytes per independent frame-pair (2 B_pyr + B_kf + B_trk, with
+            # this run's point counts and evaluation counts) x pairs / ms_per_step / peak -- per GPU
+            "step": {"algorithmic_bytes_per_step": step_bytes_alg, "b_pyr_per_frame": b_pyr, "b_kf_per_keyframe": b_kf,
+                     "b_trk_per_pair": b_trk / a.pairs, "achieved": step_bytes_alg / (elapsed / a.steps) / 1e9,
+                     "frac": step_bytes_alg / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
+            # every kernel of the step ALONE (build kernels: HIP events between the launches, one stream; k_track: kernel_ms_alone):
+            # the kernel furthest below its roofline is the one to look at next
+            "kernels": kernels,
         },
-        "collective": {"backend": "nccl (RCCL)" if use_group else None, "executed_every_step": bool(use_group),
-                       "bytes_per_rank": a.pairs * parallel.RECORD_BYTES, "us_per_all_gather_alone": gather_us,
+        "collective": {"backend": "nccl (RCCL)" if use_group else None, "executed_every_step": bool(use_group) and every == 1,
+                       "steps_per_collective": every if use_group else None, "inside_timed_region": bool(use_group),
+                       "bytes_per_rank": a.pairs * parallel.RECORD_BYTES * every, "us_per_all_gather_alone": gather_us,
                        "ranks_seen": seen, "world_size": group_size,  # all_gather of the rank ids / dist.get_world_size()
                        "error": group_error},
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},
@@ -688,6 +918,16 @@ def main():
             ref_res = hb.track(fr)  # the records every later job must repeat
             for j in [hb.submit(fr) for _ in range(3)]:  # warm-up: all three job slots exist before the clock starts
                 hb.wait(j)
+            # ... and the path itself is warm (VERDICT r04 #9/#6d: the first timed repetition ran at 16-28 GB/s, the others at
+            # 45): untimed groups of three jobs until two consecutive groups agree within 10 %, at most eight groups
+            warm = []
+            for _ in range(8):
+                t0w = time.perf_counter()
+                for j in [hb.submit(fr) for _ in range(3)]:
+                    hb.wait(j)
+                warm.append(time.perf_counter() - t0w)
+                if len(warm) >= 2 and abs(warm[-1] - warm[-2]) <= 0.1 * warm[-2]:
+                    break
             k_steps = max(8, a.steps)
             reps_h = []
             for _ in range(3):  # three repetitions, ALL reported, the median is the figure (r03: 41 vs 17 GB/s between two runs)
@@ -707,7 +947,7 @@ def main():
             step_bytes = a.pairs * 2 * a.width * a.height * (3 + (2 if scale else 4))
             hostb[tag] = {"value_incl_h2d": a.pairs * k_steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / k_steps * 1e3,
                           "h2d_bytes_per_step": step_bytes, "pcie_gbs": step_bytes * k_steps / dt_h / 1e9, "steps": k_steps,
-                          "statistic": "median of 3 repetitions",
+                          "statistic": "median of 3 repetitions", "warmup_groups_of_3_jobs_s": warm,
                           "value_incl_h2d_runs": [a.pairs * k_steps / t for t in reps_h],
                           "pcie_gbs_runs": [step_bytes * k_steps / t / 1e9 for t in reps_h]}
             del hb

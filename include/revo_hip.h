@@ -298,6 +298,11 @@ int revo_batch_track_only(revo_batch* b, const float* h_init_RT,
  * on another stream (the library orders every later consumer and the next build of the batch behind it) or to keep it outside a
  * timed tracker launch.  On a stream other than the build's it waits for the build.  No-op when nothing is pending. */
 int revo_batch_prepare(revo_batch* b, void* stream);
+/* Waits for `stream` (NULL = the batch's own), runs whatever the last build still left pending, waits for the batch's last
+ * tracker grid WHEREVER it ran, and decodes the flags of that grid's records: a record with bit 3 makes the call return
+ * REVO_ERR_HIP.  Lifetime contract: the d_results buffer of the last revo_batch_track_only / revo_batch_track must stay
+ * valid (not freed, not reused for something else) until this call or the batch's next tracker launch -- the call reads it.
+ * A later revo_batch_build* does not end that obligation (a pipelined caller builds step k+1 before it syncs step k). */
 int revo_batch_sync(revo_batch* b, void* stream);
 /* Pyramid view of frame f of the batch (owned by the batch). */
 int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out);
@@ -306,6 +311,18 @@ int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out);
 int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT,
                             revo_pair_result* d_results, void* stream, int reps,
                             float* ms_mean);
+
+/* Measurement aid (bench.py's per-kernel roofline table): every kernel of revo_batch_build_borrow + revo_batch_prepare run
+ * ALONE on the batch's own stream with HIP events between the launches; us[i] = mean duration of stage i over `reps` passes
+ * (event to event: kernel + a few us of dispatch), name[i] = the kernel ("hysteresis" = k_hyst, or the banded kernels where a
+ * level takes that path).  Leaves the batch built. */
+#define REVO_MAX_STAGES 16
+typedef struct revo_stage_times {
+  int32_t n;
+  float us[REVO_MAX_STAGES];
+  char name[REVO_MAX_STAGES][32];
+} revo_stage_times;
+int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, int reps, revo_stage_times* out);
 
 /* ---- host-buffer batches: what a producer like IOWrapperRGBD::readNextFrame hands over ------------ */
 
@@ -340,6 +357,69 @@ int revo_track_pairs_submit(revo_ctx* ctx, int n, const revo_pair_in* pairs, int
 int revo_track_pairs_wait(revo_pairs_job* job, revo_pair_out* out);
 int revo_track_pairs(revo_ctx* ctx, int n, const revo_pair_in* pairs, int depth_is_u16,
                      double depth_scale_factor, revo_pair_out* out);
+
+/* ---- the pipelined batch mode as one handle (new in round 5) ------------------------------------------------
+ *
+ * The reference owns its producer / consumer pipeline: REVO::start drains the queue an IO thread fills
+ * (system/system.cpp:96,128-284, io/iowrapperRGBD.cpp:279-288).  The batched mode's counterpart is a rotation of
+ * `depth` device-resident batches over FOUR streams the handle owns -- build | edge lists + keyframe EDT | two
+ * alternating tracker streams (the resident gate keeps two tracker grids in flight) -- so that step t+3 is built
+ * while step t+2 is prepared and steps t+1 and t are tracked.  This is the shape `bench.py` measures; the handle
+ * exists so that an integrator gets it without rebuilding the choreography (HIP multiplexes streams onto a few
+ * hardware queues, and one stream more, or the same streams created in another order, costs a third of the
+ * throughput: DESIGN.md 3.0).  revo_pipeline_create probes its streams (a 150 us kernel on one, a time stamp on
+ * another) and replaces those that share a hardware queue; revo_pipeline_info reports the outcome.
+ *
+ *   submit(t)  enqueues build, deferred work and tracker grid of step t and returns at once: a ticket and the
+ *              stream the grid runs on.  Work the caller enqueues on THAT stream before the next-but-one submit
+ *              (the result collective, a copy) runs behind the grid and before the stream's next grid: the
+ *              "after the grid" slot.  Do not create a stream of your own for it: a fifth active stream ends up
+ *              behind one of the four in a hardware queue.
+ *   wait(t)    blocks until step t and its after-grid work are complete; with host_results the n records of the
+ *              step are returned from pinned memory (a record with flag bit 3 makes it return REVO_ERR_HIP).
+ *
+ * d_bgr / d_depth: device-resident inputs of the step, [2*n_pairs][H][W][3] u8 and [2*n_pairs][H][W] depth, frame 2i =
+ * reference (keyframe) of pair i, frame 2i+1 = current (revo_batch_track).  depth_kind 0: f32 metres, BORROWED
+ * (level 0 of the depth pyramid is the caller's plane: it must stay valid and unchanged for `depth` further
+ * submits or until revo_pipeline_wait of the step); 1: f32 metres, copied; 2: raw u16 with depth_scale_factor
+ * (iowrapperRGBD.cpp:326-327).  input_ready_event: a hipEvent_t recorded behind whatever produces the inputs, or
+ * NULL when they are already complete.  h_init_RT: n_pairs x 12 floats on the host (R column-major, T) or NULL.
+ * d_results: n_pairs records in device memory, or NULL for a buffer of the handle's own (host_results).  Results
+ * are the same bits as revo_batch_track on one batch: the pipeline only changes when kernels run.
+ * One handle is driven by one host thread at a time. */
+typedef struct revo_pipeline revo_pipeline;
+typedef struct revo_pipeline_info_t {
+  int32_t batches;            /* batches in rotation (= depth)                                            */
+  int32_t pairs_per_step;
+  int32_t tracker_streams;    /* 1 or 2                                                                    */
+  int32_t distinct_hw_queues; /* how many of the handle's streams sit on pairwise distinct hardware queues
+                                 (4 = none alias; -1 = not probed: REVO_PIPE_PROBE=0)                      */
+  int32_t streams_replaced;   /* candidate streams discarded because they aliased one already kept         */
+  int32_t probes_run;
+  void* streams[4];           /* hipStream_t: tracker 0, tracker 1, build, auxiliary                       */
+  uint64_t steps_submitted;
+} revo_pipeline_info_t;
+/* depth: batches in rotation, 0 = the default (4), 1 = one batch on one stream (nothing overlaps), 2 = build
+ * next to one tracker stream.  host_results != 0: every step's records are copied to pinned host memory behind
+ * its grid and revo_pipeline_wait returns them; then a slot's step must be waited for before the slot is
+ * submitted again (`depth` steps later), else REVO_ERR_CAPACITY. */
+int revo_pipeline_create(revo_ctx* ctx, int n_pairs, int depth, int host_results, revo_pipeline** out);
+void revo_pipeline_destroy(revo_pipeline* p);
+int revo_pipeline_submit(revo_pipeline* p, const uint8_t* d_bgr, const void* d_depth, int depth_kind,
+                         double depth_scale_factor, const float* h_init_RT, revo_pair_result* d_results,
+                         void* input_ready_event, uint64_t* ticket, void** after_grid_stream);
+int revo_pipeline_wait(revo_pipeline* p, uint64_t ticket, revo_pair_result* h_results);
+/* Waits for everything submitted so far (all four streams). */
+int revo_pipeline_drain(revo_pipeline* p);
+int revo_pipeline_info(const revo_pipeline* p, revo_pipeline_info_t* out);
+/* The batch that holds step `ticket` (accessors through revo_batch_frame); valid until its slot is submitted again. */
+int revo_pipeline_batch(revo_pipeline* p, uint64_t ticket, revo_batch** out);
+/* Live timing of the dominant kernel inside the pipelined steps: every every_n-th submit carries a HIP event pair
+ * around its tracker grid, on the grid's stream (0 = off; resets the statistics).  revo_pipeline_tracker_ms: mean
+ * duration and number of the launches harvested so far (a launch is harvested when its slot is reused, waited
+ * for, or drained). */
+int revo_pipeline_time_tracker(revo_pipeline* p, int every_n);
+int revo_pipeline_tracker_ms(revo_pipeline* p, float* mean_ms, int* launches);
 
 /* ---- REVO::start sequencing (system/system.cpp:84-305) ----------------------- */
 

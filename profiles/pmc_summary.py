@@ -4,9 +4,22 @@ MI355X_MICROARCH.md "HBM") and calibrated on k_gray_depth, whose bytes are known
 usage: pmc_summary.py <fetch.db> <write.db> <pairs> <width> <height> <command string> [borrow] > summary.json
 (borrow: the build borrowed the f32 depth input, so k_gray_depth only reads BGR and writes gray)"""
 import collections
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+
+def csrc_sha16():
+    """the same hash bench.py computes: sha256 over revo_amd/csrc/*.hip|*.h (names + contents)"""
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "revo_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -25,7 +38,7 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 pairs, w, h = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-out = {"command": sys.argv[6], "unit_note": "FETCH_SIZE / WRITE_SIZE are KB per launch (rocprofv3); hbm_bytes_per_launch = "
+out = {"command": sys.argv[6], "csrc_sha16": csrc_sha16(), "commit": os.environ.get("REVO_COMMIT"), "unit_note": "FETCH_SIZE / WRITE_SIZE are KB per launch (rocprofv3); hbm_bytes_per_launch = "
        "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, checked on k_gray_depth"}
 for k in sorted(set(fetch) | set(write)):
     f, wr = fetch.get(k, 0.0), write.get(k, 0.0)

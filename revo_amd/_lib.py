@@ -101,6 +101,7 @@ def lib():
     L.revo_track_pairs.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vp]
     L.revo_batch_frame.argtypes = [vp, C.c_int, vpp]
     L.revo_batch_time_tracker.argtypes = [vp, f32p, vp, vp, C.c_int, f32p]
+    L.revo_batch_profile_build.argtypes = [vp, vp, vp, C.c_int, vp]
     L.revo_ctx_histogram_level.argtypes = [vp]
     L.revo_vo_create.argtypes = [vp, vpp]
     L.revo_vo_destroy.argtypes = [vp]
@@ -114,6 +115,16 @@ def lib():
     L.revo_vo_close.argtypes = [vp]
     L.revo_vo_wait_frame.argtypes = [vp]
     L.revo_vo_num_keyframes.argtypes = [vp]
+    L.revo_pipeline_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, vpp]
+    L.revo_pipeline_destroy.argtypes = [vp]
+    L.revo_pipeline_destroy.restype = None
+    L.revo_pipeline_submit.argtypes = [vp, vp, vp, C.c_int, C.c_double, f32p, vp, vp, C.POINTER(C.c_uint64), vpp]
+    L.revo_pipeline_wait.argtypes = [vp, C.c_uint64, vp]
+    L.revo_pipeline_drain.argtypes = [vp]
+    L.revo_pipeline_info.argtypes = [vp, vp]
+    L.revo_pipeline_batch.argtypes = [vp, C.c_uint64, vpp]
+    L.revo_pipeline_time_tracker.argtypes = [vp, C.c_int]
+    L.revo_pipeline_tracker_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
     _lib = L
     return L
 

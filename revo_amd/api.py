@@ -359,6 +359,8 @@ class BatchTracker:
         check(_lib.lib().revo_batch_track_only(self._h, ptr, d_results, stream))
 
     def sync(self, stream=None):
+        """Waits for the stream and for the batch's last tracker grid (on whichever stream it ran) and checks its records'
+        flags.  The d_results buffer of that launch must still be alive: it is read here (revo_hip.h, revo_batch_sync)."""
         check(_lib.lib().revo_batch_sync(self._h, stream))
 
     def frame(self, f, settings):
@@ -366,11 +368,99 @@ class BatchTracker:
         check(_lib.lib().revo_batch_frame(self._h, f, C.byref(h)))
         return ImgPyramidRGBD(settings, self._cam, _handle=h, _owned=False)
 
+    def profile_build(self, d_bgr, d_depth, reps=3):
+        """-> [(kernel name, mean us alone)]: every kernel of build(borrow_depth=True) + prepare(), HIP events between the
+        launches on the batch's own stream (revo_batch_profile_build)."""
+        st = StageTimes()
+        check(_lib.lib().revo_batch_profile_build(self._h, d_bgr, d_depth, reps, C.byref(st)))
+        return [(st.name[i].value.decode(), float(st.us[i])) for i in range(st.n)]
+
     def time_tracker(self, d_results, reps=5, init_RT=None, stream=None):
         keep, ptr = self._init(init_RT)
         ms = C.c_float()
         check(_lib.lib().revo_batch_time_tracker(self._h, ptr, d_results, stream, reps, C.byref(ms)))
         return ms.value
+
+
+class StageTimes(C.Structure):
+    """revo_stage_times"""
+    _fields_ = [("n", C.c_int32), ("us", C.c_float * 16), ("name", (C.c_char * 32) * 16)]
+
+
+class PipelineInfo(C.Structure):
+    """revo_pipeline_info_t"""
+    _fields_ = [("batches", C.c_int32), ("pairs_per_step", C.c_int32), ("tracker_streams", C.c_int32),
+                ("distinct_hw_queues", C.c_int32), ("streams_replaced", C.c_int32), ("probes_run", C.c_int32),
+                ("streams", C.c_void_p * 4), ("steps_submitted", C.c_uint64)]
+
+
+class Pipeline:
+    """revo_pipeline_*: the pipelined batch mode behind one handle -- `depth` resident batches rotate over four streams
+    the library owns (build | edge lists + keyframe EDT | two tracker streams), the counterpart of the reference's IO
+    thread + REVO::start loop (system.cpp:96,128-284).  submit() returns (ticket, stream): work enqueued on that stream
+    before the next-but-one submit runs behind the step's tracker grid (the slot for the result collective)."""
+
+    DEPTH_F32_BORROWED, DEPTH_F32_COPIED, DEPTH_U16 = 0, 1, 2
+
+    def __init__(self, cameraPyr, n_pairs, depth=0, host_results=False):
+        self._cam = cameraPyr
+        self.n_pairs = n_pairs
+        self.host_results = bool(host_results)
+        self._h = vp()
+        check(_lib.lib().revo_pipeline_create(cameraPyr._h, n_pairs, depth, int(bool(host_results)), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().revo_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, d_bgr, d_depth, d_results=None, init_RT=None, depth_kind=0, depth_scale_factor=1.0, input_ready_event=None):
+        """-> (ticket, stream handle the step's tracker grid runs on).  d_*: raw device pointers."""
+        keep, ptr = BatchTracker._init(init_RT)
+        ticket, stream = C.c_uint64(), vp()
+        check(_lib.lib().revo_pipeline_submit(self._h, d_bgr, d_depth, depth_kind, float(depth_scale_factor), ptr, d_results,
+                                              input_ready_event, C.byref(ticket), C.byref(stream)))
+        return ticket.value, stream.value
+
+    def wait(self, ticket):
+        """Blocks until the step (and what the caller put behind its grid) is complete; with host_results -> its records."""
+        if not self.host_results:
+            check(_lib.lib().revo_pipeline_wait(self._h, ticket, None))
+            return None
+        out = (PairResult * self.n_pairs)()
+        check(_lib.lib().revo_pipeline_wait(self._h, ticket, C.cast(out, vp)))
+        return results_from_buffer(bytes(out), self.n_pairs)
+
+    def drain(self):
+        check(_lib.lib().revo_pipeline_drain(self._h))
+
+    def info(self):
+        i = PipelineInfo()
+        check(_lib.lib().revo_pipeline_info(self._h, C.byref(i)))
+        return dict(batches=i.batches, pairs_per_step=i.pairs_per_step, tracker_streams=i.tracker_streams,
+                    distinct_hw_queues=i.distinct_hw_queues, streams_replaced=i.streams_replaced, probes_run=i.probes_run,
+                    streams=[int(x or 0) for x in i.streams], steps_submitted=int(i.steps_submitted))
+
+    def batch_frame(self, ticket, f, settings):
+        """Pyramid view of frame f of the batch that holds step `ticket` (valid until its slot is submitted again)."""
+        b, h = vp(), vp()
+        check(_lib.lib().revo_pipeline_batch(self._h, ticket, C.byref(b)))
+        check(_lib.lib().revo_batch_frame(b, f, C.byref(h)))
+        return ImgPyramidRGBD(settings, self._cam, _handle=h, _owned=False)
+
+    def time_tracker(self, every_n):
+        check(_lib.lib().revo_pipeline_time_tracker(self._h, every_n))
+
+    def tracker_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        check(_lib.lib().revo_pipeline_tracker_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
 
 class HostBatchTracker:

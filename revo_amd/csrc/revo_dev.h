@@ -131,12 +131,13 @@ void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t
 void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);      // reference-ordered list (accessor)
-void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);  // tile-ordered list + npts (hot path)
+// tile-ordered list + npts (hot path); which: bit 0 = k_tile_count, bit 1 = k_pts_tiles (the stage profiler times them apart)
+void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s, int which = 3);
 // keyframe promotion of frames f0, f0+fstride, ... (count frames)
 void launch_pyrdown_bgr(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
 void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int lvl, int dense, const uint8_t* bgr_lvl,
                         int* chunk, unsigned* cmask, int* total, int cap, float* out8, hipStream_t s);
-void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s);
+void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s, int which = 3);  // bit 0 = k_edt_cols, bit 1 = k_edt_rows
 // epoch_io: per-mailbox epoch counter kept by the owner of d_mail (zero it together with the mailbox)
 // both tracker launchers return the grid size (workgroups) they enqueued; d_resident: the device's census counter (every
 // workgroup adds 1 when it starts), nullptr = no census

@@ -26,6 +26,8 @@ static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+// used by the other translation units of the library (revo_pipeline.hip): one error string per thread
+extern "C" void revo_set_error_(const char* msg) { g_err = msg ? msg : ""; }
 #define HIPCHECK(expr)                                                                      \
   do {                                                                                      \
     hipError_t e__ = (expr);                                                                \
@@ -73,6 +75,7 @@ struct FrameSet {
   uint8_t* h_bgr = nullptr;
   float* h_depth = nullptr;
   hipEvent_t ev_ready = nullptr;  // recorded on the build stream after the last build kernel
+  hipStream_t ready_stream = nullptr;  // ... that stream (a consumer on it is ordered already)
   hipEvent_t ev_aux = nullptr;    // (batches) the keyframe EDT on the batch's side stream: not owned by the set
   bool has_aux = false;
   // (batches) the keyframes' EDT has been DEFERRED to whoever needs it first -- normally the tracker launch of the batch, on
@@ -96,11 +99,21 @@ struct Past {  // one entry of mPastPcl / mPastWorldPoses / mPastTimeStamps (tra
   size_t cap;  // points the buffer holds
 };
 
+// Experiment knobs (environment variables), read ONCE PER CONTEXT when it is created (they used to be
+// process-wide statics, so two contexts of one process could not differ): the defaults are what ships.
+struct Knobs {
+  int track_depth;     // REVO_TRACK_DEPTH (1..4, default 2; REVO_TRACK_SERIAL=1 forces 1): tracker grids the resident gate keeps in flight
+  int cluster_one;     // REVO_TRACK_CLUSTER_ONE (0 = automatic): workgroups of the single-pair launch
+  int redundant_one;   // REVO_TRACK_REDUNDANT_ONE: levels up to this many points are evaluated redundantly by the single-pair launch
+  int h2d_mode;        // REVO_H2D_STREAMS: 0 = colour and depth planes on two copy streams, 1 = one stream, 2 = swapped
+};
+
 struct revo_ctx {
   // handles (pyramids, batches, VO drivers) keep their context alive: revo_ctx_destroy only drops
   // the owner's reference, the last handle to go frees the device state
   std::atomic<int> refs{1};
   int device;
+  Knobs knobs;
   revo_pyr_settings ps; revo_opt_settings os; revo_tracker_settings ts;
   PyrGeom geom;
   TrackParams tp;
@@ -153,6 +166,7 @@ struct revo_batch {
   unsigned mail_epoch = 0;
   bool identity_uploaded = false;  // d_descs already holds the identity initial poses (nothing to upload)
   int cluster;
+  int defer = 2;                   // REVO_DEFER / REVO_EDT_DEFER, read when the batch is created (env_defer_level)
   hipStream_t stream;
   hipStream_t side = nullptr;                      // the EDT of the keyframes runs here, next to the edge lists
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -294,26 +308,24 @@ static void build_track_params(const revo_ctx* c, TrackParams* t) {
 // Tracker grids the resident gate keeps in flight per device (REVO_TRACK_DEPTH, default 2; 1 = one at a time, the round-2
 // behaviour; up to 4 for experiments with small clusters: workgroup-time per pair falls with the cluster size -- the
 // exchange and the decision are paid by every member -- but a grid of small clusters only fills a fraction of the chip).
-static int track_depth() {
-  static const int d = [] {
-    const char* e = getenv("REVO_TRACK_SERIAL");
-    if (e && *e && *e != '0') return 1;
-    return env_int("REVO_TRACK_DEPTH", 2, 1, 4);
-  }();
-  return d;
+static int env_track_depth() {
+  const char* e = getenv("REVO_TRACK_SERIAL");
+  if (e && *e && *e != '0') return 1;
+  return env_int("REVO_TRACK_DEPTH", 2, 1, 4);
 }
 static int pick_cluster(const revo_ctx* c, int n_pairs) {
   const int resident = c->num_cus * c->blocks_per_cu;
   // a batch grid takes 1/depth of what the device holds: `depth` grids are resident together
   // (depth 1 = one grid at a time: the round-2 shape, 75 % of the chip)
-  const int share = n_pairs == 1 || track_depth() == 1 ? (int)(0.75 * resident) : resident / track_depth();
+  const int depth = c->knobs.track_depth;
+  const int share = n_pairs == 1 || depth == 1 ? (int)(0.75 * resident) : resident / depth;
   int cl = share / std::max(1, n_pairs);
   // a single pair: its members share one XCD (blockIdx % 8), i.e. 32 CUs -- 16 workgroups leave half of them
   // to the build kernels of the next frame
   if (n_pairs == 1) cl = std::min(cl, 16);
   if (cl > TRACK_MAX_CLUSTER) cl = TRACK_MAX_CLUSTER;
-  if (const char* e = getenv(n_pairs == 1 ? "REVO_TRACK_CLUSTER_ONE" : "REVO_TRACK_CLUSTER")) {  // tuning knob
-    const int want = atoi(e);
+  {  // tuning knobs: REVO_TRACK_CLUSTER_ONE (per context), REVO_TRACK_CLUSTER (read when a batch is created)
+    const int want = n_pairs == 1 ? c->knobs.cluster_one : env_int("REVO_TRACK_CLUSTER", 0, 0, TRACK_MAX_CLUSTER);
     const int hard = std::min(TRACK_MAX_CLUSTER, resident / std::max(1, n_pairs));
     if (want >= 1) cl = std::min(want, std::max(1, hard));
   }
@@ -333,37 +345,48 @@ static int pick_cluster(const revo_ctx* c, int n_pairs) {
 //     launch n's workgroups fill the CUs that n-1's finished pairs free, and are themselves all resident once n-1 has
 //     drained (192 <= 256 CUs; build kernels finish in finite time).  By induction the older of the two grids is always
 //     fully resident: no cyclic wait.
-// REVO_TRACK_DEPTH=n (1..4, default 2) sets how many grids may be in flight (launch n waits for launch n-depth to
-// complete); REVO_TRACK_SERIAL=1 = depth 1 = the round-2 behaviour.  (Other PROCESSES sharing the GPU are outside this library's
-// reach: the bounded spin + flag 8 + REVO_ERR_HIP remain the answer there.)
+// REVO_TRACK_DEPTH=n (1..4, default 2; read per context) sets how many grids may be in flight (launch n waits for launch
+// n-depth to complete); REVO_TRACK_SERIAL=1 = depth 1 = the round-2 behaviour.  The chain itself is per DEVICE (the census
+// counter is) and keeps the events of the last TRACK_MAX_DEPTH launches, so contexts with different depths may share a device:
+// each launch applies its own context's depth.  (Other PROCESSES sharing the GPU are outside this library's reach: the
+// bounded spin + flag 8 + REVO_ERR_HIP remain the answer there.)
 #define TRACK_MAX_DEPTH 4
 struct TrackChain {
   std::mutex mu;
-  hipEvent_t ev[TRACK_MAX_DEPTH] = {};   // completion of the last `depth` launches (ring)
+  hipEvent_t ev[TRACK_MAX_DEPTH] = {};   // completion of the last TRACK_MAX_DEPTH launches (ring, slot = launch index % 4)
   hipStream_t st[TRACK_MAX_DEPTH] = {};
   bool has[TRACK_MAX_DEPTH] = {};
-  int n = 0;                     // launches so far
+  unsigned long long n = 0;      // launches so far
+  int depth_seen = 0;            // the depth of the first launch; `mixed` once a launch with another depth arrived
+  bool mixed = false;
   unsigned* d_resident = nullptr;
   unsigned started_total = 0;    // workgroups of all launches enqueued so far (the census value once they have all started)
 };
 static TrackChain g_chain[64];
 // launch(): enqueues the tracker grid on s and returns its workgroup count
 template <typename F>
-static int chained_track_launch(int device, hipStream_t s, F&& launch) {
+static int chained_track_launch(int device, int depth, hipStream_t s, F&& launch) {
   TrackChain& ch = g_chain[device & 63];
   std::lock_guard<std::mutex> lk(ch.mu);
-  const int depth = track_depth();
+  depth = depth < 1 ? 1 : (depth > TRACK_MAX_DEPTH ? TRACK_MAX_DEPTH : depth);
   if (!ch.ev[0]) {
     for (int i = 0; i < TRACK_MAX_DEPTH; ++i) HIPCHECK(hipEventCreateWithFlags(&ch.ev[i], hipEventDisableTiming));
     HIPCHECK(hipMalloc((void**)&ch.d_resident, 2 * sizeof(unsigned)));  // [0] census, [1] gates that timed out
     HIPCHECK(hipMemset(ch.d_resident, 0, 2 * sizeof(unsigned)));
   }
-  // slot `cur` holds launch n-depth (it must be COMPLETE: at most `depth` grids in flight), slot `prev` launch n-1 (it must
-  // be fully RESIDENT: only the newest grid is ever partially on the chip, every older one holds all its CUs and finishes
-  // whatever arrives -- no cyclic wait at any depth).  With depth 1 the two coincide: one grid at a time.
-  const int cur = ch.n % depth, prev = (ch.n + depth - 1) % depth;
-  if (ch.has[cur] && ch.st[cur] != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev[cur], 0));
-  if (depth > 1 && ch.has[prev] && ch.st[prev] != s) launch_track_gate(ch.d_resident, ch.started_total, s);
+  // launch n-depth must be COMPLETE (at most `depth` grids in flight; with one depth in use every older launch completed
+  // before it by induction -- only when contexts with DIFFERENT depths share the device are the older ring slots waited for
+  // as well), launch n-1 must be fully RESIDENT: only the newest grid is ever partially on the chip, every older one holds
+  // all its CUs and finishes whatever arrives -- no cyclic wait at any depth.  With depth 1 the two coincide: one grid at a time.
+  if (!ch.depth_seen) ch.depth_seen = depth;
+  if (depth != ch.depth_seen) ch.mixed = true;
+  for (int back = depth; back <= (ch.mixed ? TRACK_MAX_DEPTH : depth); ++back) {
+    if ((unsigned long long)back > ch.n) break;
+    const int slot = (int)((ch.n - back) % TRACK_MAX_DEPTH);
+    if (ch.has[slot] && ch.st[slot] != s) HIPCHECK(hipStreamWaitEvent(s, ch.ev[slot], 0));
+  }
+  const int prev = (int)((ch.n + TRACK_MAX_DEPTH - 1) % TRACK_MAX_DEPTH), cur = (int)(ch.n % TRACK_MAX_DEPTH);
+  if (depth > 1 && ch.n > 0 && ch.has[prev] && ch.st[prev] != s) launch_track_gate(ch.d_resident, ch.started_total, s);
   const int n_wg = launch(ch.d_resident);
   HIPCHECK(hipGetLastError());              // (a refused launch adds nothing to the census: the next gate must not wait for it)
   ch.started_total += (unsigned)n_wg;
@@ -498,6 +521,10 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   revo_ctx* c = new revo_ctx();
   c->device = device;
   c->ps = *pyr;
+  c->knobs.track_depth = env_track_depth();
+  c->knobs.cluster_one = env_int("REVO_TRACK_CLUSTER_ONE", 0, 0, TRACK_MAX_CLUSTER);
+  c->knobs.redundant_one = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
+  c->knobs.h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
   if (opt) c->os = *opt; else revo_opt_settings_default(&c->os);
   if (trk) c->ts = *trk; else revo_tracker_settings_default(&c->ts);
   std::string why;
@@ -578,7 +605,8 @@ extern "C" int revo_ctx_reserve_framesets_(revo_ctx* c, int total) {
     c->pool.push_back(fs);
   }
 }
-// used by revo_vo.hip
+extern "C" int revo_ctx_device_(const revo_ctx* c) { return c ? c->device : -1; }
+// used by revo_vo.hip / revo_pipeline.hip
 extern "C" void revo_ctx_retain_(revo_ctx* c) { if (c) ctx_ref(c); }
 extern "C" void revo_ctx_release_(revo_ctx* c) { if (c) ctx_unref(c); }
 
@@ -675,6 +703,7 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_ready, bs));
   fs->has_ready = true;
+  fs->ready_stream = bs;
   revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts, false, false};
   ctx_ref(c);
   *out = p;
@@ -866,10 +895,10 @@ static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, 
   fill_desc(c->h_desc, ref, curr, R, T);
   { int rc = wait_ready(c, ref); if (rc) return rc; rc = wait_ready(c, curr); if (rc) return rc; }
   TrackParams tp1 = tp;
-  tp1.redundant_n = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
+  tp1.redundant_n = c->knobs.redundant_one;
   const unsigned seq = c->seq_next++;
   if (c->seq_next == 0) c->seq_next = 1;
-  const int rc = chained_track_launch(c->device, c->stream, [&](unsigned* d_resident) {
+  const int rc = chained_track_launch(c->device, c->knobs.track_depth, c->stream, [&](unsigned* d_resident) {
     return launch_track_one(*c->h_desc, tp1, c->h_res + slot, c->h_eval, c->d_mail, &c->mail_epoch, pick_cluster(c, 1), c->h_seq + slot,
                             seq, d_resident, c->stream);
   });
@@ -1146,6 +1175,12 @@ extern "C" void revo_tracker_reset_past_(revo_ctx* c) {
 extern "C" int revo_tracker_past_size(const revo_ctx* c) { return c ? (int)c->past.size() : 0; }
 
 // -------------------------------------------------------------------- batch --
+static int env_defer_level() {  // read when a batch is created
+  if (!env_int("REVO_EDT_DEFER", 1, 0, 1)) return 0;
+  // default 2 (round 4: 87.1 k -> 95.6 k frames/s together with a stream of their own for the deferred kernels and four batches
+  // in rotation, profiles/r04_ab_defer_levels.txt; 3 was measured too: 92.8 k)
+  return env_int("REVO_DEFER", 2, 0, 3);
+}
 extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   if (!c || !out || n_pairs <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
   HIPCHECK(hipSetDevice(c->device));
@@ -1169,6 +1204,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
     HIPCHECK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   }
   b->cluster = pick_cluster(c, n_pairs);
+  b->defer = env_defer_level();
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
   for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false, false});
@@ -1204,6 +1240,16 @@ static int batch_wait_tracker(revo_batch* b, hipStream_t s) {
   if (b->has_trk && b->trk_stream != s) HIPCHECK(hipStreamWaitEvent(s, b->ev_trk, 0));
   return REVO_OK;
 }
+// A tracker grid on a stream other than the build's: ordered behind the build whatever was deferred (with
+// REVO_DEFER=0 / REVO_EDT_DEFER=0 / REVO_BUILD_FORK=1 nothing is pending, so run_pending_edt orders nothing -- and the edge
+// lists, counts and DT planes the grid reads are written by the build stream).  Cheap and idempotent.
+static int batch_wait_build(revo_batch* b, hipStream_t s) {
+  // (with work deferred to the first consumer, run_pending_edt does the ordering: it either runs that work on s behind the
+  // "built" event or waits for the "prepared" event of whoever ran it -- no second barrier packet on the tracker's stream)
+  if (b->defer >= 1 && !b->side) return REVO_OK;
+  if (b->fs->has_ready && b->fs->ready_stream != s) HIPCHECK(hipStreamWaitEvent(s, b->fs->ev_ready, 0));
+  return REVO_OK;
+}
 static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
   HIPCHECK(hipEventRecord(b->ev_trk, s));
   b->has_trk = true;
@@ -1211,12 +1257,6 @@ static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
   return REVO_OK;
 }
 
-static int batch_defer_level() {
-  if (!env_int("REVO_EDT_DEFER", 1, 0, 1)) return 0;
-  // default 2 (round 4: 87.1 k -> 95.6 k frames/s together with a stream of their own for the deferred kernels and four batches
-  // in rotation, profiles/r04_ab_defer_levels.txt; 3 was measured too: 92.8 k)
-  return env_int("REVO_DEFER", 2, 0, 3);
-}
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   const PyrGeom& g = b->ctx->geom;
   if (b->side) {
@@ -1229,13 +1269,13 @@ static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
     HIPCHECK(hipEventRecord(b->ev_join, b->side));
     b->fs->ev_aux = b->ev_join; b->fs->has_aux = true;
     launch_tile_points(g, b->fs->p, b->fs->B, s);
-  } else if (batch_defer_level() >= 1) {
+  } else if (b->defer >= 1) {
     // Work left to the batch's first consumer (run_pending_edt: the tracker launch on ITS stream, revo_batch_prepare on a
     // stream of the caller's choice, an accessor, revo_batch_sync) -- the build stream is the critical chain of the
     // pipelined step.  REVO_DEFER = 1: the keyframes' EDT (97 us less on the build stream; round 3);  2: the edge lists of all
     // frames too (they only depend on the edge maps and nothing on the build stream reads them);  3: hysteresis + fill-in as
     // well (the build ends behind the Canny NMS).  REVO_EDT_DEFER=0 / REVO_DEFER=0: nothing is deferred.
-    const int lvl = batch_defer_level();
+    const int lvl = b->defer;
     if (lvl < 2) launch_tile_points(g, b->fs->p, b->fs->B, s);
     std::lock_guard<std::mutex> lk(b->fs->edt_mu);
     b->fs->hyst_pending = lvl >= 3;
@@ -1261,11 +1301,12 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }     // ... or its deferred EDT, on whichever stream ran it
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }              // ... and its tracker grid still reads lists and DT planes
   // (Measured and not kept: the two halves of the batch as two concurrent kernel chains -- 78.4 k -> 70.5 k frames/s.)
-  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || batch_defer_level() < 3);
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || b->defer < 3);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;
+  b->fs->ready_stream = s;
   for (auto& v : b->views) { v.table_built = false; v.ref_list_built = false; }
   return REVO_OK;
 }
@@ -1309,10 +1350,11 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
+  { int rc1 = batch_wait_build(b, s); if (rc1) return rc1; }
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));  // the keyframes' EDT (side stream of the build)
   { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; }   // ... or deferred to this launch
   b->last_results = d_results;
-  rc = chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
+  rc = chained_track_launch(b->ctx->device, b->ctx->knobs.track_depth, s, [&](unsigned* d_resident) {
     return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
   });
   if (rc) return rc;
@@ -1331,11 +1373,12 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false, 0, -1,
-                b->side || batch_defer_level() < 3);
+                b->side || b->defer < 3);
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
   b->fs->has_ready = true;
+  b->fs->ready_stream = s;
   for (auto& v : b->views) { v.table_built = false; v.ref_list_built = false; }
   return REVO_OK;
 }
@@ -1357,6 +1400,8 @@ extern "C" int revo_batch_sync(revo_batch* b, void* stream) {
   // A record with bit 3 carries no pose (its workgroups could not exchange partial sums: device shared with
   // another process): that is an error of the call, not something to find by decoding flags.
   if (b->last_results) {
+    //  the grid that wrote these records may have run on ANOTHER stream than s: finish it before reading
+    { int rc3 = batch_wait_tracker(b, s); if (rc3) return rc3; }
     HIPCHECK(hipMemcpyAsync(b->h_flags, b->last_results, sizeof(revo_pair_result) * b->n_pairs, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     b->last_results = nullptr;  // decoded once: the caller may free or reuse that buffer after this call
@@ -1465,7 +1510,7 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   // device-buffer batches a third of their throughput, so the library does not ask for it; swapping the planes' streams
   // helped in one order of events and not in another: the mapping depends on the process's stream history).
   // REVO_H2D_STREAMS: 1 = one copy stream for both planes, 2 = planes swapped (experiments).
-  static const int h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
+  const int h2d_mode = c->knobs.h2d_mode;
   hipStream_t cs = c->copy_stream, cs2 = h2d_mode == 1 ? c->copy_stream : c->copy_stream2;  // cs: colour, cs2: depth
   if (h2d_mode == 2) std::swap(cs, cs2);
   // Any failure below must not leave the slot busy for ever (three of those and the context only ever answers
@@ -1544,6 +1589,80 @@ extern "C" int revo_track_pairs(revo_ctx* c, int n, const revo_pair_in* pairs, i
   return revo_track_pairs_wait(j, out);
 }
 
+// Every kernel of the batch build ALONE, HIP events between the launches on one stream, mean of `reps` passes: the per-kernel
+// table of bench.py's roofline (VERDICT r04 #6b: the kernel furthest below its roofline must be visible in the driver's record).
+// Leaves the batch built exactly like revo_batch_build_borrow + revo_batch_prepare.
+extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, const float* d_depth, int reps, revo_stage_times* out) {
+  if (!b || !d_bgr || !d_depth || !out || reps <= 0) return fail(REVO_ERR_INVALID_ARG, "bad argument");
+  revo_ctx* c = b->ctx;
+  HIPCHECK(hipSetDevice(c->device));
+  hipStream_t s = b->stream;
+  if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
+  { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }
+  { int rc = batch_wait_tracker(b, s); if (rc) return rc; }
+  memset(out, 0, sizeof(*out));
+  PyrGeom g = c->geom;
+  g.frame0 = 0;
+  FrameSet* fs = b->fs;
+  const int B = fs->B, L = g.n_levels;
+  fs->p.depth[0] = const_cast<float*>(d_depth);
+  struct Stage { const char* name; int a, w; };
+  std::vector<Stage> st;
+  st.push_back({"k_gray_depth", 0, 0});
+  for (int l = 1; l < L; ++l) st.push_back({"k_pyrdown", l, 0});
+  st.push_back({"k_canny_nms4", 0, 0});
+  st.push_back({"hysteresis", 0, 0});
+  st.push_back({"k_fill", 0, 0});
+  st.push_back({"k_tile_count", 0, 1});
+  st.push_back({"k_pts_tiles", 0, 2});
+  st.push_back({"k_edt_cols", 0, 1});
+  st.push_back({"k_edt_rows", 0, 2});
+  const int n = (int)st.size();
+  if (n > REVO_MAX_STAGES) return fail(REVO_ERR_CAPACITY, "too many stages");
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
+  std::vector<double> sum(n, 0.0);
+  for (int r = 0; r < reps; ++r) {
+    HIPCHECK(hipEventRecord(ev[0], s));
+    for (int i = 0; i < n; ++i) {
+      const std::string nm = st[i].name;
+      if (nm == "k_gray_depth") launch_gray_depth(g, fs->p, d_bgr, d_depth, nullptr, 0.f, B, s);
+      else if (nm == "k_pyrdown") launch_pyrdown(g, fs->p, st[i].a, B, s);
+      else if (nm == "k_canny_nms4") launch_canny_nms(g, fs->p, B, s);
+      else if (nm == "hysteresis") launch_hyst(g, fs->p, B, s);
+      else if (nm == "k_fill") launch_fill(g, fs->p, B, s);
+      else if (nm == "k_tile_count" || nm == "k_pts_tiles") launch_tile_points(g, fs->p, B, s, st[i].w);
+      else launch_keyframe(g, fs->p, 0, 2, b->n_pairs, s, st[i].w);
+      HIPCHECK(hipGetLastError());
+      HIPCHECK(hipEventRecord(ev[i + 1], s));
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+      float ms = 0.f;
+      HIPCHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      sum[i] += ms * 1e3;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  out->n = n;
+  for (int i = 0; i < n; ++i) {
+    out->us[i] = (float)(sum[i] / reps);
+    if (std::string(st[i].name) == "k_pyrdown") snprintf(out->name[i], sizeof(out->name[i]), "k_pyrdown[%d]", st[i].a);
+    else snprintf(out->name[i], sizeof(out->name[i]), "%s", st[i].name);
+  }
+  {  // the state a build + prepare leaves behind
+    std::lock_guard<std::mutex> lk(fs->edt_mu);
+    fs->edt_pending = false; fs->pts_pending = false; fs->hyst_pending = false;
+    HIPCHECK(hipEventRecord(fs->ev_edt, s));
+    fs->has_edt = true; fs->edt_stream = s;
+  }
+  HIPCHECK(hipEventRecord(fs->ev_ready, s));
+  fs->has_ready = true; fs->ready_stream = s;
+  fs->has_aux = false;
+  for (auto& v : b->views) { v.table_built = false; v.ref_list_built = false; }
+  return REVO_OK;
+}
+
 extern "C" int revo_batch_frame(revo_batch* b, int frame, revo_pyr** out) {
   if (!b || !out || frame < 0 || frame >= 2 * b->n_pairs) return fail(REVO_ERR_INVALID_ARG, "bad frame index");
   *out = &b->views[frame];
@@ -1561,12 +1680,13 @@ extern "C" int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT, re
   if (rc) return rc;
   TrackParams tp = b->ctx->tp;
   tp.eval_only = 0;
+  { int rc1 = batch_wait_build(b, s); if (rc1) return rc1; }
   if (b->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, b->ev_join, 0));
   { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; }
   float total = 0.f;
   for (int r = 0; r < reps; ++r) {  // events bracket exactly one kernel on its own stream
     HIPCHECK(hipEventRecord(b->ev0, s));
-    rc = chained_track_launch(b->ctx->device, s, [&](unsigned* d_resident) {
+    rc = chained_track_launch(b->ctx->device, b->ctx->knobs.track_depth, s, [&](unsigned* d_resident) {
       return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
     });
     if (rc) return rc;

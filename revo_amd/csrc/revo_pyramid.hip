@@ -2109,10 +2109,10 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 }
 
 // the hot path's edge list: tile-ordered, for the tracker (the reference-ordered list is launch_compact, on demand)
-void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_tile_count, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
+void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s, int which) {
+  if (which & 1) hipLaunchKernelGGL(k_tile_count, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
   const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
-  hipLaunchKernelGGL(k_pts_tiles, dim3(groups * B), dim3(32 * PT_TILES), 0, s, g, p);
+  if (which & 2) hipLaunchKernelGGL(k_pts_tiles, dim3(groups * B), dim3(32 * PT_TILES), 0, s, g, p);
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
@@ -2139,16 +2139,16 @@ void launch_colored_pcl(const PyrGeom& g, const FramePlanes& p, int frame, int l
                      chunk, cmask, total, cap, (float4*)out8);
 }
 
-void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s) {
+void launch_keyframe(const PyrGeom& g, const FramePlanes& p, int f0, int fstride, int count, hipStream_t s, int which) {
   int strips = 0;
   for (int l = 0; l < g.n_levels; ++l) {
     const int ncols = EDT_THREADS / EDT_COL_GROUPS(g.lv[l].h);
     strips += (g.lv[l].w + ncols - 1) / ncols;
   }
-  hipLaunchKernelGGL(k_edt_cols, dim3(strips * count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride, count);
+  if (which & 1) hipLaunchKernelGGL(k_edt_cols, dim3(strips * count), dim3(EDT_THREADS), 0, s, g, p, f0, fstride, count);
   size_t rows_lds = 0;
   for (int l = 0; l < g.n_levels; ++l) rows_lds = std::max(rows_lds, (size_t)g.lv[l].edt_rows * (3 * g.lv[l].w + 8) * sizeof(int));
-  hipLaunchKernelGGL(k_edt_rows, dim3(g.total_edt_blocks, 1, count), dim3(256), rows_lds, s, g, p, f0, fstride);
+  if (which & 2) hipLaunchKernelGGL(k_edt_rows, dim3(g.total_edt_blocks, 1, count), dim3(256), rows_lds, s, g, p, f0, fstride);
 }
 
 // The float4 table is only materialised for the returnOptimizationStructure accessor: the

@@ -46,6 +46,27 @@ def gather_records(local_records, world, group=None, out=None):
     return out
 
 
+def gather_every_default(world):
+    """Steps per collective.  N = 1: every step (nothing to couple).  N > 1: every SECOND step -- the collective sits in the
+    after-grid slot of a tracker stream, in front of that stream's next grid, so every collective is a point where a rank
+    that runs behind delays the others' next-but-one grid; carrying two steps' records per collective halves those points
+    and lets a rank lag a full step in between (latency-bound, no reduction, no ring)."""
+    return 1 if world == 1 else 2
+
+
+def gather_window(t, every, start=0):
+    """After step t has been submitted (steps of the current phase count from `start`): (first_step, n_steps) of the
+    collective that is due now, or None."""
+    every = max(1, int(every))
+    return (t - every + 1, every) if (t - start + 1) % every == 0 else None
+
+
+def gather_tail(end, every, start=0):
+    """The steps of the phase [start, end) that no window has covered: (first_step, n) or None."""
+    rem = (end - start) % max(1, int(every))
+    return (end - rem, rem) if rem else None
+
+
 def max_over_ranks(seconds, world, device="cpu"):
     import torch
     import torch.distributed as dist

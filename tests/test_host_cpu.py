@@ -196,7 +196,11 @@ def _check_dry_run_line(rec, world, pairs, steps):
     assert rec["collective"]["ranks_seen"] == list(range(world)) and rec["collective"]["world_size"] == world
     # every rank's own step time travels in the line (a straggler GPU must be visible in the first real N > 1 run)
     assert len(rec["ms_per_step_per_rank"]) == world and max(rec["ms_per_step_per_rank"]) <= rec["ms_per_step"] * 1.0001
-    assert rec["collective"]["bytes_per_rank"] == pairs * 96
+    every = rec["collective"]["steps_per_collective"]
+    assert every == (1 if world == 1 else 2)  # N > 1: the records of two steps per collective (parallel.gather_every_default)
+    assert rec["collective"]["bytes_per_rank"] == pairs * 96 * every
+    # every step of the warm-up and of the timed loop was gathered and checked (record by record, rank order, step index)
+    assert rec["collective"]["steps_gathered_and_checked"] == steps + rec["warmup"]
 
 
 def test_bench_rank_plumbing_world2_self_spawned():
@@ -223,6 +227,46 @@ def test_bench_rank_plumbing_world2_under_torchrun():
     rec = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(rec) == 1  # rank 0 only
     _check_dry_run_line(rec[0], 2, 3, 2)
+
+
+def test_gather_schedule_windows_cover_every_step_once():
+    """parallel.gather_window / gather_tail: every step of a phase travels in exactly one collective, whatever the phase
+    start and the window size."""
+    from revo_amd import parallel
+    for every in (1, 2, 3, 4):
+        for start, end in ((0, 7), (5, 25), (3, 4), (6, 6)):
+            seen = []
+            for t in range(start, end):
+                w = parallel.gather_window(t, every, start)
+                if w:
+                    assert w[1] == every and w[0] + every - 1 == t
+                    seen += list(range(w[0], w[0] + w[1]))
+            tail = parallel.gather_tail(end, every, start)
+            if tail:
+                assert 0 < tail[1] < every and tail[0] + tail[1] == end
+                seen += list(range(tail[0], tail[0] + tail[1]))
+            assert seen == list(range(start, end)), (every, start, end, seen)
+    assert parallel.gather_every_default(1) == 1 and parallel.gather_every_default(8) == 2
+
+
+def test_bench_world8_a_late_rank_does_not_serialise_the_others():
+    """VERDICT r04 #12 / SURVEY 8(e): the step's only collective sits in the after-grid slot of a tracker stream, i.e. in front
+    of that stream's NEXT grid two steps later -- it is never waited for by the host in the step loop.  World size 8 on gloo,
+    a stubbed 20 ms step, rank 3 is 14 ms late in ONE step: the other ranks' own step loops (`ms_loop_per_rank`, each rank's
+    clock before the final drain) must not grow by that delay -- they keep a step of slack -- while rank 3's does."""
+    steps, step_ms, delay_ms = 10, 20.0, 14.0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-cpu", "--steps", str(steps),
+                        "--warmup", "2", "--pairs", "2", "--dry-run-step-ms", str(step_ms), "--dry-run-delay-rank", "3",
+                        "--dry-run-delay-ms", str(delay_ms)], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    rec = _one_json_line(r.stdout)
+    _check_dry_run_line(rec, 8, 2, steps)
+    loops = rec["ms_loop_per_rank"]
+    others = [x for i, x in enumerate(loops) if i != 3]
+    assert loops[3] >= steps * step_ms + 0.9 * delay_ms, loops
+    # not serialised behind the late rank: the others stay clearly below "their own work + the delay"
+    assert max(others) < loops[3] - 0.5 * delay_ms, loops
+    assert rec["collective"]["steps_gathered_and_checked"] == steps + 2
 
 
 def test_ab_bench_variant_specs():
