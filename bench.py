@@ -398,7 +398,11 @@ def main():
         n_seq = a.single_stream_frames
         # a seeded synthetic camera sweep (TUM-like inter-frame motion: ~4 mm, 1 deg per frame)
         seq = synth.make_sequence(7, s, n_seq, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
-        stream_frames = [(f[0], f[1], f[2]) for f in seq]
+        # the frames sit in PAGE-LOCKED host memory, as a decoder thread that owns its buffers leaves them: revo_vo_submit then
+        # lets the DMA engine read them in place (no host-side staging copy; pageable frames still work, through a staging copy)
+        def pin(x):
+            return torch.from_numpy(np.ascontiguousarray(x)).pin_memory().numpy()
+        stream_frames = [(pin(f[0]), pin(f[1]), f[2]) for f in seq]
         # warm-up: two full-length runs (pools, first touch of every slot, code paths).  One run in about six is ~28 % slow at
         # points that move with the number of warm-up runs but do not disappear (profiles/r04_single_stream_12_runs.txt: twelve
         # runs after 1 / 2 / 3 warm-up runs) -- not the collector (disabled inside the runs), not a fixed run index; a host-side
@@ -1010,8 +1014,8 @@ def main():
                                 "speedup_vs_cpu_oracle_2core_pipelined": (n / dt_seq / cpu_seq_2core) if cpu_seq else None,
                                 "speedup_vs_cpu_oracle": (n / dt_seq / cpu_seq) if cpu_seq else None,
                                 "note": "sequential REVO::start sequencing (revo_vo_*) via the host-buffer C ABI on a seeded synthetic "
-                                        "sweep: host copy + H2D + pyramid on the IO thread, trackFrames + quality vote "
-                                        "per frame on the consumer thread (PCIe-inclusive)"}
+                                        "sweep, frames in page-locked host memory: H2D (in place, no staging copy) + pyramid on the IO "
+                                        "thread, trackFrames + quality vote per frame on the consumer thread (PCIe-inclusive)"}
 
     # ---- CPU baseline: the oracle (plain-C port of the reference's algorithm) on the same batch
     # with the reference's thread model -- the IO thread builds the pyramids, the main thread promotes keyframes and

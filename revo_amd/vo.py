@@ -144,11 +144,13 @@ class REVO:
         return out
 
     def tum_lines(self):
-        """REVO::writePose, system.cpp:76-80: 'ts tx ty tz qx qy qz qw'."""
+        """REVO::writePose, system.cpp:76-80: 'ts tx ty tz qx qy qz qw', std::fixed.  The stream's precision is set to 9
+        AFTER the time stamp has been written and stays set (std::setprecision is sticky): the first line carries the time
+        stamp with the default 6 decimals, every later line with 9 -- reproduced as the reference's file has it."""
         out = []
-        for ts, M in self.poses:
+        for i, (ts, M) in enumerate(self.poses):
             q = _quat_xyzw(M[:3, :3])
-            out.append("%.6f %.9f %.9f %.9f %.9f %.9f %.9f %.9f" % ((ts,) + tuple(M[:3, 3]) + tuple(q)))
+            out.append(("%.6f" if i == 0 else "%.9f") % ts + " %.9f %.9f %.9f %.9f %.9f %.9f %.9f" % (tuple(M[:3, 3]) + tuple(q)))
         return out
 
 

@@ -652,6 +652,50 @@ def test_1280x960_five_levels(api, ro):
     assert er < 2e-3 and et < 3e-3
 
 
+def test_1280x960_five_levels_batch_of_eight_pairs(api, ro):
+    """BASELINE configs[3] at its bench shape: EIGHT 1280x960 / 5-level pairs through one batch and through
+    the pipeline handle -- every pair's pose against the oracle, the pyramids of two frames bit for bit (the banded hysteresis
+    is the default at this size), and the pipelined records identical to the batch's."""
+    import torch
+    s = ImgPyramidSettings.scaled(1280, 960, 5, hist_patch=(20, 10, 5, 0, 0, 0))
+    n = 8
+    pairs = synth.make_pairs(range(2100, 2100 + n), s)
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).cuda()
+    dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).cuda()
+    bt = api.BatchTracker(cam, n)
+    d_res = torch.zeros(n * 96, dtype=torch.uint8, device="cuda")
+    bt.track(bgr.data_ptr(), dep.data_ptr(), d_res.data_ptr())
+    bt.sync()
+    raw = d_res.cpu().numpy().tobytes()
+    res = api.results_from_buffer(raw, n)
+    ot = ro.Tracker(s)
+    outside = 0
+    for i, p in enumerate(pairs):
+        o_ref, o_cur = ro.Pyramid(s, *p["ref"]), ro.Pyramid(s, *p["curr"])
+        o_ref.makeKeyframe()
+        if i < 1:
+            compare_pyramid("big8_ref%d" % i, bt.frame(2 * i, s), o_ref, s, True)
+            compare_pyramid("big8_cur%d" % i, bt.frame(2 * i + 1, s), o_cur, s, False)
+        r_o = ot.trackFrames(o_ref, o_cur, np.eye(3), np.zeros(3))
+        assert res[i]["flags"] & (2 | 4 | 8) == 0
+        dr, dt = rot_angle(res[i]["R"], r_o["R"]), float(np.linalg.norm(res[i]["T"] - r_o["T"]))
+        outside += not (dr < ROT_TOL and dt < TRANS_TOL)
+        assert dr < 5e-3 and dt < 5e-3, (i, dr, dt)
+        er, et = synth.pose_error(res[i]["R"], res[i]["T"], p["T_ref_curr"])
+        assert er < 3e-3 and et < 5e-3, (i, er, et)
+    assert outside <= 1, "%d of %d pairs outside 1e-4 rad / 1e-4 m" % (outside, n)
+    pipe = api.Pipeline(cam, n, depth=3)
+    outs = [torch.zeros(n * 96, dtype=torch.uint8, device="cuda") for _ in range(5)]
+    for o in outs:
+        pipe.submit(bgr.data_ptr(), dep.data_ptr(), o.data_ptr())
+    pipe.drain()
+    for o in outs:
+        assert o.cpu().numpy().tobytes() == raw
+    pipe.close()
+
+
 def test_pool_reuse_and_async_build_stress(api, ro):
     """Pyramids are built asynchronously on a second stream into pooled, recycled device sets.  Interleave
     create / track / destroy so sets are reused while earlier work is still in flight: every result must

@@ -60,6 +60,8 @@ def test_vo_matches_oracle_trajectory_and_keyframes():
     assert len(lines) == len(frames) and len(lines[3].split()) == 8
     q = np.array(lines[3].split()[4:], np.float64)
     assert abs(np.linalg.norm(q) - 1) < 1e-5
+    # std::setprecision(9) is sticky: 6 decimals of the time stamp on the first line only (system.cpp:79)
+    assert len(lines[0].split()[0].split(".")[1]) == 6 and all(len(ln.split()[0].split(".")[1]) == 9 for ln in lines[1:])
 
 
 def test_run_tum_cli_on_a_synthetic_tum_dataset(tmp_path, monkeypatch):
@@ -135,3 +137,34 @@ def test_bench_runs_a_tum_layout_folder(tmp_path):
     assert t["frames"] == 12 and t["frames_per_s"] > 0 and t["keyframes"] >= 1
     assert t["ate_rmse_vs_groundtruth_m"] < 5e-3
     assert t["trajectory_rmse_gpu_vs_oracle_m"] < 1e-3
+
+
+def test_page_locked_frames_are_read_in_place_and_give_the_same_bits(monkeypatch):
+    """revo_pyramid_create / revo_vo_submit with the caller's rows in page-locked memory: the H2D reads them in place on a copy
+    stream and the call returns once the device-side clone exists (imgpyramidrgbd.cpp:51,54: the reference clones its inputs).
+    Same trajectory, bit for bit, as pageable frames through the staging copy -- also when the caller overwrites its buffer
+    right after submit (the clone semantics), and with the path switched off (REVO_DIRECT_H2D=0)."""
+    import torch
+    from revo_amd import synth, vo
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    frames = synth.make_sequence(9, s, 24, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(1.0), 0])
+    plain = [(f[0], f[1], f[2]) for f in frames]
+    want = vo.REVO(s).run(plain)
+    # one pinned buffer pair, refilled for every frame: only correct if submit really returns after the clone
+    pb = torch.empty((s.height, s.width, 3), dtype=torch.uint8).pin_memory()
+    pd = torch.empty((s.height, s.width), dtype=torch.float32).pin_memory()
+
+    def refilled():
+        for bgr, dep, ts in plain:
+            pb.numpy()[...] = bgr
+            pd.numpy()[...] = dep
+            yield pb.numpy(), pd.numpy(), ts
+    got = vo.REVO(s).run(refilled(), io_thread=False)
+    assert len(got) == len(want)
+    for (Ma, ka), (Mb, kb) in zip(got, want):
+        assert ka == kb and np.array_equal(Ma, Mb)
+    monkeypatch.setenv("REVO_DIRECT_H2D", "0")
+    off = vo.REVO(s).run(refilled(), io_thread=False)  # (a new context: the knob is read per context)
+    for (Ma, ka), (Mb, kb) in zip(off, want):
+        assert ka == kb and np.array_equal(Ma, Mb)

@@ -170,3 +170,38 @@ def test_vo_sequencing_keyframes_and_ate():
     assert synth.ate_rmse(est, gt) < 0.01
     t = vo.times()
     assert t[0] > 0 and t[1] > 0 and t[2] > 0
+
+
+def test_reference_lm_is_only_defined_up_to_the_rounding_of_its_own_sums():
+    """The CPU-only half of the tracker's tolerance statement: the oracle against ITSELF, once with the
+    reference's float sums accumulated sequentially (LGSX.h:392-398, optimizer.cpp:129-133) and once with the same terms
+    accumulated in double (ro_set_accum_double).  Same algorithm, same inputs, same order -- only the rounding of the sums
+    differs -- yet the borderline `error < lastErr` / `error / lastErr > 0.999` decisions (optimizer.cpp:273-278) flip on a
+    sizeable share of the pairs: the accept / reject sequences differ, and the final poses then sit at different points inside
+    the LM's convergence slack.  This is the distribution the GPU tests see against the float oracle
+    (tests/test_gpu_variants.py); no parallel implementation can do better than the reference does against itself."""
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    trk = ro.Tracker(s, OptimizerSettings(), TrackerSettings())
+    L = ro.lib()
+    n, same, dr, dt = 40, 0, [], []
+    try:
+        for seed in range(3000, 3000 + n):
+            pair = synth.make_pair(seed, s)
+            ref, cur = ro.Pyramid(s, *pair["ref"]), ro.Pyramid(s, *pair["curr"])
+            ref.makeKeyframe()
+            L.ro_set_accum_double(0)
+            a = trk.trackFrames(ref, cur, np.eye(3), np.zeros(3))
+            L.ro_set_accum_double(1)
+            b = trk.trackFrames(ref, cur, np.eye(3), np.zeros(3))
+            same += list(a["evals"][:3]) == list(b["evals"][:3])
+            dr.append(synth.rot_angle(a["R"], b["R"]))
+            dt.append(float(np.linalg.norm(a["T"] - b["T"])))
+    finally:
+        L.ro_set_accum_double(0)
+    dr, dt = np.array(dr), np.array(dt)
+    print("oracle float vs double sums, %d pairs: identical evaluation counts %d, within 1e-5: %d, max %.2e rad %.2e m"
+          % (n, same, int(((dr < 1e-5) & (dt < 1e-5)).sum()), dr.max(), dt.max()))
+    assert same < n, "float and double sums took the same decisions everywhere: the tolerance statement would need another cause"
+    assert same >= n // 4
+    assert ((dr < 1e-4) & (dt < 1e-4)).sum() >= 0.9 * n and dr.max() < 5e-3 and dt.max() < 5e-3
+    assert np.median(dr) < 1e-5 and np.median(dt) < 1e-5
