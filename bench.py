@@ -75,6 +75,21 @@ def cpu_info():
     return model, allowed
 
 
+def resident_gate_state(device):
+    """The library's resident gate (revo_host.hip): workgroups of tracker grids that have started / gates that gave up waiting /
+    workgroups enqueued.  A healthy run has no time-outs, and census == enqueued once the device is idle."""
+    import ctypes as C
+    from revo_amd import _lib
+    L = _lib.lib()
+    if not hasattr(L, "revo_debug_census_"):
+        return None
+    o = (C.c_uint * 3)()
+    L.revo_debug_census_.argtypes = [C.c_int, C.POINTER(C.c_uint)]
+    if L.revo_debug_census_(int(device), o) != 0:
+        return None
+    return {"census": int(o[0]), "timeouts": int(o[1]), "enqueued": int(o[2])}
+
+
 def baseline_config(w, h, levels, pairs, world):
     """Which BASELINE.json configuration a run IS, by geometry (VERDICT r04 #10), not by world size alone."""
     if (w, h, levels) == (640, 480, 4):
@@ -638,6 +653,10 @@ def main():
         pipe.drain()
         ms_live, n_live = pipe.tracker_ms()
         pipe.time_tracker(0)
+    gate = resident_gate_state(local_rank)
+    if gate and gate["timeouts"]:
+        print("bench: WARNING: %d resident gates gave up waiting (census %d of %d enqueued workgroups): tracker grids were "
+              "held back for the gate's time-out -- the line below does not describe a healthy run" % (gate["timeouts"], gate["census"], gate["enqueued"]), file=sys.stderr)
     # one batch for the measurements outside the timed region (stage split, k_track alone, point counts)
     bt = api.BatchTracker(cam, a.pairs) if use_lib else bts[(counter[0] - 1) % nbuf]
 
@@ -885,6 +904,7 @@ def main():
                        "ranks_seen": seen, "world_size": group_size,  # all_gather of the rank ids / dist.get_world_size()
                        "error": group_error},
         "stages_ms": {"pyramids_and_keyframes": ms_build, "tracker": ms_trk_stage},
+        "resident_gate": gate,  # after the timed region: time-outs must be 0
         "pose_error_vs_ground_truth": {"rot_rad_median": rot_med, "trans_m_median": tr_med},
         "mean_edge_points_lvl0": float(npts[:, 0].mean()),
         "mean_evals_per_level": [float(x) for x in evals.mean(0)],

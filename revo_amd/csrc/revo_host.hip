@@ -375,7 +375,10 @@ static int chained_track_launch(int device, int depth, hipStream_t s, F&& launch
   if (!ch.ev[0]) {
     for (int i = 0; i < TRACK_MAX_DEPTH; ++i) HIPCHECK(hipEventCreateWithFlags(&ch.ev[i], hipEventDisableTiming));
     HIPCHECK(hipMalloc((void**)&ch.d_resident, 2 * sizeof(unsigned)));  // [0] census, [1] gates that timed out
+    // (hipMemset on device memory is asynchronous to the host and runs on the NULL stream; the tracker streams are non-blocking
+    // streams, so the first grid could count itself into the census BEFORE the zeroing lands: finish it here, once per device)
     HIPCHECK(hipMemset(ch.d_resident, 0, 2 * sizeof(unsigned)));
+    HIPCHECK(hipDeviceSynchronize());
   }
   // launch n-depth must be COMPLETE (at most `depth` grids in flight; with one depth in use every older launch completed
   // before it by induction -- only when contexts with DIFFERENT depths share the device are the older ring slots waited for
@@ -407,6 +410,16 @@ extern "C" int revo_debug_gate_timeouts_(int device) {
   unsigned v = 0;
   if (hipMemcpy(&v, ch.d_resident + 1, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -2;
   return (int)v;
+}
+// diagnostics: out3 = {census (workgroups that have started), gates that timed out, workgroups of all launches enqueued so far}.
+// After hipDeviceSynchronize census == enqueued in a healthy process.
+extern "C" int revo_debug_census_(int device, unsigned out3[3]) {
+  TrackChain& ch = g_chain[device & 63];
+  std::lock_guard<std::mutex> lk(ch.mu);
+  if (!ch.d_resident || !out3) return -1;
+  if (hipMemcpy(out3, ch.d_resident, 2 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  out3[2] = ch.started_total;
+  return 0;
 }
 static size_t mail_bytes(int n_pairs, int cluster) { return sizeof(unsigned long long) * (size_t)n_pairs * 2 * cluster * TRACK_NVAL; }
 
@@ -560,6 +573,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   HIPCHECK(hipMemset(c->d_vote_done, 0, sizeof(unsigned)));
   HIPCHECK(hipHostMalloc((void**)&c->h_hist8, sizeof(int) * 16));  // hist[4], overlaps[4], sequence word
   memset(c->h_hist8, 0, sizeof(int) * 16);
+  HIPCHECK(hipDeviceSynchronize());  // the zeroing above runs on the NULL stream; the context's streams are non-blocking
   guard.c = nullptr;
   *out = c;
   return REVO_OK;
@@ -1249,6 +1263,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   HIPCHECK(hipMalloc((void**)&b->d_descs, sizeof(PairDesc) * n_pairs));
   for (int i = 0; i < n_pairs; ++i) fill_desc(&b->h_descs[i], &b->views[2 * i], &b->views[2 * i + 1], nullptr, nullptr);
   HIPCHECK(hipStreamSynchronize(c->stream));  // frameset_create's memset
+  HIPCHECK(hipStreamSynchronize(nullptr));    // the mailbox zeroing (NULL stream; the batch's streams are non-blocking)
   guard.b = nullptr;
   *out = b;
   return REVO_OK;

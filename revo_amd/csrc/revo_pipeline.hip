@@ -226,6 +226,7 @@ extern "C" int revo_pipeline_create(revo_ctx* ctx, int n_pairs, int depth, int h
     PCHECK(hipMemset(sl.d_res, 0, sizeof(revo_pair_result) * n_pairs));
     if (p->host_results) PCHECK(hipHostMalloc((void**)&sl.h_res, sizeof(revo_pair_result) * n_pairs));
   }
+  PCHECK(hipStreamSynchronize(nullptr));  // the zeroing above (NULL stream; the pipeline's streams are non-blocking)
   guard.p = nullptr;
   *out = p;
   return REVO_OK;
