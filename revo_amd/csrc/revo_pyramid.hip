@@ -381,6 +381,9 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t C, uint32_t S) {  // S sub
   return up | dn | S;
 }
 
+// (-DREVO_HYST_PROFILE: thread 0's clock after every phase, one printf per level-0 frame at the end.  The printf of workgroups
+// that finish early disturbs the LATE phases of the ones still running -- device printf is a host call -- so only the phases of
+// undisturbed frames are meaningful: profiles/r05_hyst_phase_profile.txt shows both.)
 #ifdef REVO_HYST_PROFILE
 #define HP(i) if (threadIdx.x == 0) hp[i] = clock64()
 #define HA(i) if (threadIdx.x == 0) { const long long now_ = clock64(); ha[i] += now_ - hlast; hlast = now_; }
@@ -442,7 +445,7 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
   // candidate bitmap is not in LDS (big levels), the flood fill below does the job.
   bool done = false;
 #ifdef REVO_HYST_PROFILE
-  int dbg_runs = -1;
+  int dbg_runs = -1, dbg_t = 0, dbg_a = 0;
 #endif
   if (C_IN_LDS) {
     unsigned short* Bs = reinterpret_cast<unsigned short*>(Cl + nwords);          // runs before word i (nwords + 1 entries)
@@ -453,6 +456,10 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
     const int cap_keep = (table_words - e_words) / 2;  // up to here the tables end below E
     __shared__ int s_wsum[HYST_THREADS / 64];
     __shared__ int s_total, s_promoted;
+#ifdef REVO_HYST_PROFILE
+    __shared__ int s_dbg[4];
+    if (tid < 4) s_dbg[tid] = 0;
+#endif
     auto weak = [&](int wi) -> uint32_t { return Cl[wi]; };
     auto starts = [](uint32_t wk) -> uint32_t { return wk & ~(wk << 1); };         // first pixel of every run
     const float inv_wpr = 1.0f / (float)wpr;
@@ -600,6 +607,7 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
           }
           __syncthreads();
         }
+        HA(6);
         // components that touch an edge pixel (strong, or promoted in another band): flag the root.  Words (not
         // runs) are dealt to the threads here: one neighbourhood per word, its runs found from the bitmap
         for (int wi = wa + tid; wi < wb; wi += HYST_THREADS) {
@@ -618,11 +626,18 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
           for (uint32_t m = starts(wk); m; m &= m - 1, ++me)
             if (touched & m & (0u - m)) {
               uint32_t* root = &parent[parent[me] & 0xffffu];  // parent[me] is the root's key since the flattening pass
+#ifdef REVO_HYST_PROFILE
+              atomicAdd(&s_dbg[0], 1);
+              if (!(*root & FLAG)) atomicAdd(&s_dbg[1], 1);
+#endif
               if (!(*root & FLAG)) atomicOr(root, FLAG);      // (a big component is flagged by hundreds of runs: read first)
             }
         }
         __syncthreads();
         HA(4);
+#ifdef REVO_HYST_PROFILE
+        dbg_t = s_dbg[0]; dbg_a = s_dbg[1];
+#endif
         // a weak run is an edge iff its root is flagged: it leaves the weak bitmap (E = S | (C & ~Cl))
         bool any = false;
         for (int wi = wa + tid; wi < wb; wi += HYST_THREADS) {
@@ -799,8 +814,8 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
 #ifdef REVO_HYST_PROFILE
   HP(7);
   if (threadIdx.x == 0 && l == 0 && f < 64)
-    printf("hyst f=%d: load %lld uf_total %lld [scan %lld record %lld link %lld compress %lld flag %lld resolve %lld] runs %d sweeps %d bands %d uf %d\n", f,
-           hp[1] - hp[0], hp[5] - hp[1], ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], dbg_runs, dbg_sweeps, dbg_bands, (int)done);
+    printf("hyst f=%d: load %lld uf_total %lld [scan %lld record %lld link %lld compress %lld flag %lld resolve %lld] runs %d sweeps %d bands %d uf %d rebuild %lld out %lld hist %lld touched %d atomics %d\n", f,
+           hp[1] - hp[0], hp[5] - hp[1], ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], dbg_runs, dbg_sweeps, dbg_bands, (int)done, ha[6], hp[6] - hp[5], hp[7] - hp[6], dbg_t, dbg_a);
 #endif
 }
 // n_items = levels x frames of the launch.  only_flagged = 0: one workgroup per (level, frame), level-major (workgroup ids go
