@@ -156,6 +156,9 @@ int pick_streams(revo_pipeline* p, int want, std::vector<hipStream_t>* out) {
   }
   p->distinct_queues = (int)kept.size();
   p->streams_replaced = (int)aliased.size();
+  if ((int)kept.size() < want)  // (say it once, loudly: the pipeline still works, its stages only stop overlapping)
+    fprintf(stderr, "revo_pipeline: only %d of the %d streams sit on distinct hardware queues (GPU_MAX_HW_QUEUES < 4?): stages that share a "
+                    "queue run one after the other\n", (int)kept.size(), want);
   // not enough distinct queues: fill up with aliasing streams (still correct, only slower) and say so in revo_pipeline_info
   while ((int)kept.size() < want && !aliased.empty()) { kept.push_back(aliased.front()); aliased.erase(aliased.begin()); }
   p->discarded = aliased;
