@@ -653,6 +653,7 @@ def main():
         pipe.drain()
         ms_live, n_live = pipe.tracker_ms()
         pipe.time_tracker(0)
+        pipe_info = pipe.info()  # (steps_submitted = warm-up + timed steps)
     gate = resident_gate_state(local_rank)
     if gate and gate["timeouts"]:
         print("bench: WARNING: %d resident gates gave up waiting (census %d of %d enqueued workgroups): tracker grids were "
