@@ -325,8 +325,8 @@ def main():
                          "points (round 4's loop, kept for A/B experiments with --track-streams / --edt-streams / --build-streams)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="steps per RCCL all_gather (the records of that many steps travel in one collective, in the after-grid slot "
-                         "of the last of them); 0 = automatic: 1 at N = 1, 2 at N > 1 (ranks then synchronise every second step "
-                         "only: a rank may lag a full step without stalling the others' tracker streams)")
+                         "of the last of them); 0 = the default, 2 at every N (ranks then meet every second step only: a rank may lag "
+                         "a full step without stalling the others' tracker streams; N = 1 runs the same schedule); 1 = one per step")
     ap.add_argument("--dry-run-delay-rank", type=int, default=-1, help="--dry-run-cpu: this rank sleeps --dry-run-delay-ms in one step")
     ap.add_argument("--dry-run-delay-ms", type=float, default=0.0)
     ap.add_argument("--dry-run-step-ms", type=float, default=0.0, help="--dry-run-cpu: duration of the stubbed step")
@@ -373,6 +373,9 @@ def main():
         z = np.load(cache)
         if len(z["rb"]) < len(jobs):
             raise SystemExit("bench: %s holds %d pairs, %d are needed (delete it or lower --input-batches)" % (cache, len(z["rb"]), len(jobs)))
+        if tuple(z["rb"].shape[1:]) != (a.height, a.width, 3) or tuple(z["rd"].shape[1:]) != (a.height, a.width):
+            raise SystemExit("bench: %s holds %dx%d frames, this run is %dx%d (one cache file per geometry)"
+                             % (cache, z["rb"].shape[2], z["rb"].shape[1], a.width, a.height))
         rendered = [(z["rb"][i], z["rd"][i], z["cb"][i], z["cd"][i], z["gt"][i]) for i in range(len(jobs))]
     elif nproc > 1:
         import multiprocessing as mp

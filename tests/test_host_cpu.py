@@ -197,7 +197,7 @@ def _check_dry_run_line(rec, world, pairs, steps):
     # every rank's own step time travels in the line (a straggler GPU must be visible in the first real N > 1 run)
     assert len(rec["ms_per_step_per_rank"]) == world and max(rec["ms_per_step_per_rank"]) <= rec["ms_per_step"] * 1.0001
     every = rec["collective"]["steps_per_collective"]
-    assert every == (1 if world == 1 else 2)  # N > 1: the records of two steps per collective (parallel.gather_every_default)
+    assert every == 2  # the records of two steps per collective at every world size (parallel.gather_every_default)
     assert rec["collective"]["bytes_per_rank"] == pairs * 96 * every
     # every step of the warm-up and of the timed loop was gathered and checked (record by record, rank order, step index)
     assert rec["collective"]["steps_gathered_and_checked"] == steps + rec["warmup"]
@@ -246,7 +246,7 @@ def test_gather_schedule_windows_cover_every_step_once():
                 assert 0 < tail[1] < every and tail[0] + tail[1] == end
                 seen += list(range(tail[0], tail[0] + tail[1]))
             assert seen == list(range(start, end)), (every, start, end, seen)
-    assert parallel.gather_every_default(1) == 1 and parallel.gather_every_default(8) == 2
+    assert parallel.gather_every_default(1) == 2 and parallel.gather_every_default(8) == 2
 
 
 def test_bench_world8_a_late_rank_does_not_serialise_the_others():
