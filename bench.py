@@ -28,16 +28,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def csrc_sha16():
-    """Identity of the kernel sources a measurement was taken with: sha256 over revo_amd/csrc/*.hip|*.h (names + contents).
-    profiles/pmc_summary.py stamps it into the PMC summary; a summary taken with other sources is not quoted as `traffic`."""
+KERNEL_SOURCES = ("revo_pyramid.hip", "revo_track.hip", "revo_dev.h", "revo_div.h")  # everything the device code is compiled from
+
+
+def kernel_sha16():
+    """Identity of the DEVICE code a measurement was taken with: sha256 over the kernel translation units and the headers they
+    include (names + contents).  profiles/pmc_summary.py stamps it into the PMC summary; a summary taken with other kernels is
+    not quoted as `traffic` (host-side edits -- revo_host.hip, revo_pipeline.hip -- do not change a kernel's bytes per launch)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "revo_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -489,7 +492,7 @@ def main():
     TIME_EVERY = int(os.environ.get('REVO_BENCH_TIME_EVERY', '4' if a.steps >= 16 else '1'))
     gathered = [None, None]  # the last collective: (tensor with every rank's records in rank order, (first step, n steps))
     d_alls = {}              # (steps in the window, stream) -> the collective's output buffer
-    ev_grid = [torch.cuda.Event() for _ in range(8)]  # grid of step t done (cross-stream order of a multi-step window)
+    ev_grid = [torch.cuda.Event() for _ in range(max(8, every + 2))]  # grid of step t done (cross-stream order of a multi-step window)
     ext_streams = {}
 
     def ext(handle):
@@ -764,21 +767,21 @@ def main():
     # collected inside this process).  The summary carries the hash of the kernel sources it was taken with: a summary of other
     # sources is NOT quoted (the constant must not go stale silently).
     traffic, traffic_src, traffic_commit = None, None, None
-    src_now = csrc_sha16()
+    src_now = kernel_sha16()
     for pmc_name in ("r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest committed pass of this workload
         pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_file) and a.pairs == 32 and a.width == 640 and a.levels == 4:
             try:
                 pmc = json.load(open(pmc_file))
-                if pmc.get("csrc_sha16") != src_now:
+                if pmc.get("kernel_sha16") != src_now:
                     traffic_src = ("none: profiles/%s was taken with kernel sources %s, this run has %s -- re-run the PMC passes "
-                                   "(profiles/README.md)" % (pmc_name, pmc.get("csrc_sha16", "(unstamped)"), src_now))
+                                   "(profiles/README.md)" % (pmc_name, pmc.get("kernel_sha16", "(unstamped)"), src_now))
                     continue
                 traffic = float(next(v for k, v in pmc.items() if k.startswith("k_track"))["hbm_bytes_per_launch"])
                 traffic_commit = pmc.get("commit")
                 traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of the default pipelined "
                                "command; a committed measurement of the builder's, not taken inside this run; same kernel "
-                               "sources: csrc_sha16 %s)" % (pmc_name, src_now))
+                               "sources: kernel_sha16 %s)" % (pmc_name, src_now))
                 break
             except Exception:
                 traffic = None
@@ -884,7 +887,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": traffic_src, "traffic_commit": traffic_commit, "csrc_sha16": src_now,
+            "traffic_source": traffic_src, "traffic_commit": traffic_commit, "kernel_sha16": src_now,
             "algorithmic_bytes_per_launch": b_trk, "kernel_ms": ms_track, "kernel_ms_alone": ms_track_alone,
             "frac_alone": b_trk / (ms_track_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # two tracker grids are in flight (resident gate): a launch lasts longer than the interval at which launches

@@ -371,9 +371,10 @@ int revo_track_pairs(revo_ctx* ctx, int n, const revo_pair_in* pairs, int depth_
  * another) and replaces those that share a hardware queue; revo_pipeline_info reports the outcome.
  *
  *   submit(t)  enqueues build, deferred work and tracker grid of step t and returns at once: a ticket and the
- *              stream the grid runs on.  Work the caller enqueues on THAT stream before the next-but-one submit
- *              (the result collective, a copy) runs behind the grid and before the stream's next grid: the
- *              "after the grid" slot.  Do not create a stream of your own for it: a fifth active stream ends up
+ *              stream the grid runs on.  Work the caller enqueues on THAT stream before the next submit that uses
+ *              the same tracker stream (the next-but-one with two tracker streams, i.e. depth >= 3; the next one
+ *              otherwise) runs behind the grid and before the stream's next grid (the result collective, a copy):
+ *              the "after the grid" slot.  Do not create a stream of your own for it: a fifth active stream ends up
  *              behind one of the four in a hardware queue.
  *   wait(t)    blocks until step t and its after-grid work are complete; with host_results the n records of the
  *              step are returned from pinned memory (a record with flag bit 3 makes it return REVO_ERR_HIP).

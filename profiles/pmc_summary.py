@@ -11,14 +11,16 @@ import sqlite3
 import sys
 
 
-def csrc_sha16():
-    """the same hash bench.py computes: sha256 over revo_amd/csrc/*.hip|*.h (names + contents)"""
+KERNEL_SOURCES = ("revo_pyramid.hip", "revo_track.hip", "revo_dev.h", "revo_div.h")
+
+
+def kernel_sha16():
+    """the same hash bench.py computes: sha256 over the kernel translation units and their headers (names + contents)"""
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "revo_amd", "csrc")
     h = hashlib.sha256()
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -38,7 +40,7 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 pairs, w, h = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-out = {"command": sys.argv[6], "csrc_sha16": csrc_sha16(), "commit": os.environ.get("REVO_COMMIT"), "unit_note": "FETCH_SIZE / WRITE_SIZE are KB per launch (rocprofv3); hbm_bytes_per_launch = "
+out = {"command": sys.argv[6], "kernel_sha16": kernel_sha16(), "commit": os.environ.get("REVO_COMMIT"), "unit_note": "FETCH_SIZE / WRITE_SIZE are KB per launch (rocprofv3); hbm_bytes_per_launch = "
        "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, checked on k_gray_depth"}
 for k in sorted(set(fetch) | set(write)):
     f, wr = fetch.get(k, 0.0), write.get(k, 0.0)

@@ -321,11 +321,12 @@ extern "C" int revo_pipeline_wait(revo_pipeline* p, uint64_t ticket, revo_pair_r
   if (ticket > p->submitted) return fail(REVO_ERR_INVALID_ARG, "no such step");
   Slot& sl = p->slots[(ticket - 1) % p->nb];
   if (sl.ticket != ticket) {
-    // the slot has moved on: the step is complete on the device (the slot's next build waited for its grid)
+    // The slot has moved on.  With host results the records are gone: an error.  Otherwise wait for the tracker stream the step
+    // ran on (streams are in order: everything the step and its after-grid slot enqueued lies in front of what is there now);
+    // the newer step that holds the slot is NOT finalized by this -- its after-grid slot stays open.
     if (h_out || p->host_results)
       return fail(REVO_ERR_INVALID_ARG, "step " + std::to_string(ticket) + ": its records have been overwritten by a later step");
-    { int rc = finalize_slot(p, sl); if (rc) return rc; }
-    PCHECK(hipEventSynchronize(sl.ev_done));
+    PCHECK(hipStreamSynchronize(p->s_trk[(ticket - 1) % (unsigned long long)p->ntrk]));
     return REVO_OK;
   }
   { int rc = finalize_slot(p, sl); if (rc) return rc; }
