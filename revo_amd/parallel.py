@@ -51,7 +51,7 @@ def gather_every_default(world):
     that stream's next grid, so every collective is a point where a rank that runs behind delays the others' next-but-one grid;
     carrying two steps' records per collective halves those points and lets a rank lag a full step in between (SURVEY 8e:
     latency-bound, no reduction, no ring).  The same schedule at N = 1 and N = 8: weak scaling compares identical per-GPU work
-    (measured at N = 1, round 5: 97.0 k frames/s against 94.6 k with one collective per step)."""
+    (at N = 1 the schedule makes no measurable difference: profiles/r05_ab_gather_every.txt)."""
     return 2
 
 
