@@ -803,8 +803,9 @@ def main():
               "k_pts_tiles": nframes * (SP / 8 + SP / 8 + 4 * SN + 16 * SN),
               "k_edt_cols": a.pairs * (SP / 8 + 2 * SP),
               "k_edt_rows": a.pairs * (2 * SP + 4 * SP)}
-    for l in range(1, a.levels):
-        kbytes["k_pyrdown[%d]" % l] = nframes * (5.0 * P[l - 1] + 5.0 * P[l] + P[l - 1] / 8)
+    for l in range(1, a.levels):  # the two halves of cv::pyrDown + FilterSubsampleWithHoles (launched apart since round 5)
+        kbytes["k_pyrdown_gray[%d]" % l] = nframes * (1.0 * P[l - 1] + 1.0 * P[l])
+        kbytes["k_pyrdown_depth[%d]" % l] = nframes * (4.0 * P[l - 1] + 4.0 * P[l] + P[l - 1] / 8)
     kernels = []
     try:
         for name, us in bt.profile_build(d_bgr.data_ptr(), d_dep.data_ptr(), reps=3):

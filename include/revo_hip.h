@@ -316,7 +316,7 @@ int revo_batch_time_tracker(revo_batch* b, const float* h_init_RT,
  * ALONE on the batch's own stream with HIP events between the launches; us[i] = mean duration of stage i over `reps` passes
  * (event to event: kernel + a few us of dispatch), name[i] = the kernel ("hysteresis" = k_hyst, or the banded kernels where a
  * level takes that path).  Leaves the batch built. */
-#define REVO_MAX_STAGES 16
+#define REVO_MAX_STAGES 24
 typedef struct revo_stage_times {
   int32_t n;
   float us[REVO_MAX_STAGES];

@@ -384,7 +384,7 @@ class BatchTracker:
 
 class StageTimes(C.Structure):
     """revo_stage_times"""
-    _fields_ = [("n", C.c_int32), ("us", C.c_float * 16), ("name", (C.c_char * 32) * 16)]
+    _fields_ = [("n", C.c_int32), ("us", C.c_float * 24), ("name", (C.c_char * 32) * 24)]
 
 
 class PipelineInfo(C.Structure):

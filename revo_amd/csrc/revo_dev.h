@@ -126,7 +126,8 @@ struct EvalOut {
 // ---- launchers (defined in the kernel translation units) -------------------
 void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,
                        const uint16_t* d_depth_u16, float u16_alpha, int B, hipStream_t s);
-void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s);
+// parts: 3 = gray + depth in one launch, 1 = the gray half (Canny's input), 2 = the depth half (depth level + the source level's validity bits)
+void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s, int parts = 3);
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);

@@ -170,6 +170,7 @@ struct revo_batch {
   bool identity_uploaded = false;  // d_descs already holds the identity initial poses (nothing to upload)
   int cluster;
   int defer = 2;                   // REVO_DEFER / REVO_EDT_DEFER, read when the batch is created (env_defer_level)
+  int split_depth = 1;             // REVO_SPLIT_DEPTH (default 1): with the lists deferred, the depth half of the pyramid is deferred with them
   hipStream_t stream;
   hipStream_t side = nullptr;                      // the EDT of the keyframes runs here, next to the edge lists
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -505,13 +506,14 @@ static void frameset_destroy(FrameSet* fs) {
 // with_points = false: stops after fillInEdges; the caller enqueues launch_tile_points itself (batches run it next to the EDT)
 static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
                           const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false,
-                          bool with_points = true, int frame0 = 0, int nframes = -1, bool with_hyst = true) {
+                          bool with_points = true, int frame0 = 0, int nframes = -1, bool with_hyst = true, bool gray_only = false) {
   PyrGeom g = c->geom;
   g.frame0 = frame0;
   const int B = nframes < 0 ? fs->B : nframes;
   fs->p.depth[0] = (borrow_depth && d_depth_f32) ? const_cast<float*>(d_depth_f32) : fs->own_depth0;
   launch_gray_depth(g, fs->p, d_bgr, d_depth_f32, d_depth_u16, alpha, B, s);
-  for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, B, s);
+  // gray_only (batches that leave their edge lists to the first consumer): the depth half of the pyramid is left to it too
+  for (int l = 1; l < g.n_levels; ++l) launch_pyrdown(g, fs->p, l, B, s, gray_only ? 1 : 3);
   launch_canny_nms(g, fs->p, B, s);
   if (!with_hyst) return;  // (batches with REVO_DEFER = 3: the rest is left to the first consumer, run_pending_edt)
   launch_hyst(g, fs->p, B, s);
@@ -663,7 +665,13 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
   if (fs->hyst_pending) { launch_hyst(c->geom, fs->p, fs->B, s); launch_fill(c->geom, fs->p, fs->B, s); fs->hyst_pending = false; }
   // (the edge lists and the EDT do not depend on each other; running the EDT first -- next to the memory-bound first kernels of
   // the following build instead of its VALU-bound NMS -- was measured equal: profiles/r04_ab_aux_order.txt)
-  if (fs->pts_pending) { launch_tile_points(c->geom, fs->p, fs->B, s); fs->pts_pending = false; }
+  if (fs->pts_pending) {
+    // ... with the depth half of the pyramid in front of them (nothing on the build stream reads the coarser depth levels or the
+    // validity bits: they feed the edge lists only)
+    for (int l = 1; l < c->geom.n_levels; ++l) launch_pyrdown(c->geom, fs->p, l, fs->B, s, 2);
+    launch_tile_points(c->geom, fs->p, fs->B, s);
+    fs->pts_pending = false;
+  }
   launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_edt, s));
@@ -1255,6 +1263,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   }
   b->cluster = pick_cluster(c, n_pairs);
   b->defer = env_defer_level();
+  b->split_depth = env_int("REVO_SPLIT_DEPTH", 1, 0, 1);
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
   for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false, false});
@@ -1308,6 +1317,9 @@ static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
   return REVO_OK;
 }
 
+// the depth half of the pyramid travels with the deferred edge lists (REVO_DEFER >= 2, no side stream; REVO_SPLIT_DEPTH=0 keeps it
+// in the build: an experiment knob read when the batch is created)
+static bool batch_splits_depth(const revo_batch* b) { return !b->side && b->defer >= 2 && b->split_depth; }
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   const PyrGeom& g = b->ctx->geom;
   if (b->side) {
@@ -1352,7 +1364,7 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }     // ... or its deferred EDT, on whichever stream ran it
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }              // ... and its tracker grid still reads lists and DT planes
   // (Measured and not kept: the two halves of the batch as two concurrent kernel chains -- 78.4 k -> 70.5 k frames/s.)
-  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || b->defer < 3);
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || b->defer < 3, batch_splits_depth(b));
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
@@ -1424,7 +1436,7 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false, 0, -1,
-                b->side || b->defer < 3);
+                b->side || b->defer < 3, batch_splits_depth(b));
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
@@ -1659,11 +1671,14 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
   fs->p.depth[0] = const_cast<float*>(d_depth);
   struct Stage { const char* name; int a, w; };
   std::vector<Stage> st;
+  // (the order a pipelined batch runs them in: the gray half of the pyramid, Canny, fill-in on the build stream; the depth half,
+  // the edge lists and the keyframes' EDT on the first consumer's)
   st.push_back({"k_gray_depth", 0, 0});
-  for (int l = 1; l < L; ++l) st.push_back({"k_pyrdown", l, 0});
+  for (int l = 1; l < L; ++l) st.push_back({"k_pyrdown_gray", l, 1});
   st.push_back({"k_canny_nms4", 0, 0});
   st.push_back({"hysteresis", 0, 0});
   st.push_back({"k_fill", 0, 0});
+  for (int l = 1; l < L; ++l) st.push_back({"k_pyrdown_depth", l, 2});
   st.push_back({"k_tile_count", 0, 1});
   st.push_back({"k_pts_tiles", 0, 2});
   st.push_back({"k_edt_cols", 0, 1});
@@ -1678,7 +1693,7 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
     for (int i = 0; i < n; ++i) {
       const std::string nm = st[i].name;
       if (nm == "k_gray_depth") launch_gray_depth(g, fs->p, d_bgr, d_depth, nullptr, 0.f, B, s);
-      else if (nm == "k_pyrdown") launch_pyrdown(g, fs->p, st[i].a, B, s);
+      else if (nm == "k_pyrdown_gray" || nm == "k_pyrdown_depth") launch_pyrdown(g, fs->p, st[i].a, B, s, st[i].w);
       else if (nm == "k_canny_nms4") launch_canny_nms(g, fs->p, B, s);
       else if (nm == "hysteresis") launch_hyst(g, fs->p, B, s);
       else if (nm == "k_fill") launch_fill(g, fs->p, B, s);
@@ -1698,7 +1713,7 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
   out->n = n;
   for (int i = 0; i < n; ++i) {
     out->us[i] = (float)(sum[i] / reps);
-    if (std::string(st[i].name) == "k_pyrdown") snprintf(out->name[i], sizeof(out->name[i]), "k_pyrdown[%d]", st[i].a);
+    if (std::string(st[i].name).rfind("k_pyrdown", 0) == 0) snprintf(out->name[i], sizeof(out->name[i]), "%s[%d]", st[i].name, st[i].a);
     else snprintf(out->name[i], sizeof(out->name[i]), "%s", st[i].name);
   }
   {  // the state a build + prepare leaves behind

@@ -92,6 +92,11 @@ __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ 
 // in LDS one byte per thread-iteration with a div/mod each: ~250 VALU per output pixel.)
 // Separable [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8.  Source width is a multiple of 8.
 // ---------------------------------------------------------------------------
+// GRAY / DEPTH (round 5): the two halves are independent -- the gray half feeds Canny, i.e. the build stream's critical chain, the
+// depth half (78.6 of the 98 MB the level-1 launch reads) only feeds the edge lists.  A batch build that leaves its edge lists
+// to the first consumer (REVO_DEFER >= 2) launches the gray half alone and leaves the depth half to that consumer as well
+// (run_pending_edt): same threads, same arithmetic, same bits, two launches.  The single-frame API keeps the fused launch.
+template <bool GRAY, bool DEPTH>
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
                                                  int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst, int frame0,
                                                  uint8_t* __restrict__ vsrc, float dmin, float dmax) {
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
   int hs[7][4];            // horizontal sums of source rows 2*oy-2 .. 2*oy+4 at the 4 output columns
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
-    if (r < 2 * nrows + 3) {
+    if (GRAY && r < 2 * nrows + 3) {
       const uint32_t* row = srcw + (size_t)reflect101(2 * oy - 2 + r, sh) * swords;
       uint32_t w0 = row[max(w1i - 1, 0)];
       const uint32_t w1 = row[w1i], w2 = row[w1i + 1];
@@ -136,13 +141,16 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     if (q >= nrows) break;
-    uint32_t packed = 0;
+    if (GRAY) {
+      uint32_t packed = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int v = hs[2 * q][j] + hs[2 * q + 4][j] + 4 * (hs[2 * q + 1][j] + hs[2 * q + 3][j]) + 6 * hs[2 * q + 2][j];
-      packed |= (uint32_t)((v + 128) >> 8) << (8 * j);
+      for (int j = 0; j < 4; ++j) {
+        const int v = hs[2 * q][j] + hs[2 * q + 4][j] + 4 * (hs[2 * q + 1][j] + hs[2 * q + 3][j]) + 6 * hs[2 * q + 2][j];
+        packed |= (uint32_t)((v + 128) >> 8) << (8 * j);
+      }
+      reinterpret_cast<uint32_t*>(dst + (size_t)(oy + q) * dw)[gx] = packed;
     }
-    reinterpret_cast<uint32_t*>(dst + (size_t)(oy + q) * dw)[gx] = packed;
+    if (!DEPTH) continue;
     // depth: mean of the positive samples of each 2x2 block, reference order
     const float* d0 = dsrc + (size_t)(2 * (oy + q)) * sw + 8 * gx;
     const float4 a0 = *reinterpret_cast<const float4*>(d0), a1 = *reinterpret_cast<const float4*>(d0 + 4);
@@ -2044,12 +2052,15 @@ void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_
                      p.depth[0], npix, g.frame0);
 }
 
-void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s) {
+void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s, int parts) {
   const LevelGeom& d = g.lv[lvl];
   const LevelGeom& sl = g.lv[lvl - 1];
   dim3 grid(((d.w / 4) * ((d.h + 1) / 2) + 255) / 256, 1, B);
-  hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h,
-                     p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max);
+#define PYRDOWN_ARGS p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h, p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max
+  if (parts == 1) hipLaunchKernelGGL((k_pyrdown<true, false>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
+  else if (parts == 2) hipLaunchKernelGGL((k_pyrdown<false, true>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
+  else hipLaunchKernelGGL((k_pyrdown<true, true>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
+#undef PYRDOWN_ARGS
 }
 
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
