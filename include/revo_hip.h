@@ -292,7 +292,8 @@ int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const uint16_t* d_
                          double depth_scale_factor, void* stream);
 int revo_batch_track_only(revo_batch* b, const float* h_init_RT,
                           revo_pair_result* d_results, void* stream);
-/* Runs, on `stream`, whatever part of the last build was left to the batch's first consumer (default: the 3-D edge lists,
+/* Runs, on `stream`, whatever part of the last build was left to the batch's first consumer (default: the depth levels >= 1 of the
+ * pyramid, imgpyramidrgbd.h:218-249, which only the edge lists read; the 3-D edge lists,
  * imgpyramidrgbd.cpp:199-226, and the keyframes' distance transforms, imgpyramidrgbd.cpp:231-252 -- the build stream is the
  * critical one of a pipelined caller).  revo_batch_track_only does this itself on ITS stream; call this first to run that work
  * on another stream (the library orders every later consumer and the next build of the batch behind it) or to keep it outside a
