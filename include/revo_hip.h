@@ -423,6 +423,40 @@ int revo_pipeline_batch(revo_pipeline* p, uint64_t ticket, revo_batch** out);
 int revo_pipeline_time_tracker(revo_pipeline* p, int every_n);
 int revo_pipeline_tracker_ms(revo_pipeline* p, float* mean_ms, int* launches);
 
+/* ---- Multi-GPU: the result gather behind the C ABI --------------------------------------------
+ * The reference is a single-process CPU program (main.cpp:22-47) and has no collective; the batched mode shards
+ * independent frame-pairs over the GPUs of a node, ONE PROCESS PER GPU, and its only exchange is an all-gather of
+ * the 96-byte pair records over RCCL / xGMI.  A communicator is created like an MPI-style NCCL program does it:
+ * rank 0 calls revo_comm_unique_id and ships the 128 bytes to the other ranks by whatever the host has (MPI, a
+ * file, a socket, torch.distributed's store); every rank then calls revo_comm_create (ncclCommInitRank on the
+ * context's device: a collective).  RCCL is loaded at run time (dlopen: $REVO_RCCL_LIB, a copy the process
+ * already carries -- PyTorch bundles one --, librccl.so.1); a box without RCCL still loads the library and only
+ * these calls fail (REVO_ERR_HIP, revo_last_error says why). */
+typedef struct revo_comm revo_comm;
+#define REVO_COMM_ID_BYTES 128
+/* REVO_OK iff an RCCL library is loadable; path (optional) = what was loaded, version = ncclGetVersion. */
+int revo_comm_available(char* path_out, size_t path_cap, int* version_out);
+int revo_comm_unique_id(uint8_t id[REVO_COMM_ID_BYTES]);
+int revo_comm_create(revo_ctx* ctx, const uint8_t id[REVO_COMM_ID_BYTES], int world_size, int rank, revo_comm** out);
+void revo_comm_destroy(revo_comm* c);
+int revo_comm_world(const revo_comm* c, int* world_size, int* rank);
+/* ncclAllGather of n_records records per rank, enqueued on `stream` (hipStream_t): d_recv holds
+ * world_size * n_records records, rank-major.  Nothing is reduced; the records travel as bytes. */
+int revo_comm_allgather_records(revo_comm* c, const revo_pair_result* d_send, revo_pair_result* d_recv,
+                                int n_records, void* stream);
+/* The pipeline enqueues the collective itself, in the after-grid slot: steps are grouped into windows of `every`
+ * (1..8) consecutive steps; the grids of a window write their records into a send buffer of the handle's, and
+ * behind the window's LAST grid one all-gather moves them to window slot (k % ring) of d_gathered -- device memory,
+ * ring * world_size * every * n_pairs records, laid out [ring][rank][step in window][pair].  revo_pipeline_wait
+ * (ticket of the window's last step) covers the collective; a slot is overwritten `ring` (2..16) windows later.
+ * With a communicator attached revo_pipeline_submit's d_results may be NULL (non-NULL: the step's own records are
+ * copied there as well).  comm = NULL detaches.  Attach / detach drain the pipeline.  Every rank must submit the
+ * same number of steps.  revo_pipeline_flush_comm gathers an incomplete last window (*steps_valid of its `every`
+ * steps carry records of this run; 0 = the last window was complete and nothing was enqueued) into *slot; it is a
+ * collective too (all ranks, same point) and the next submit starts a new window. */
+int revo_pipeline_set_comm(revo_pipeline* p, revo_comm* comm, int every, revo_pair_result* d_gathered, int ring);
+int revo_pipeline_flush_comm(revo_pipeline* p, int* steps_valid, int* slot);
+
 /* ---- REVO::start sequencing (system/system.cpp:84-305) ----------------------- */
 
 /* The reference runs two threads: IOWrapperRGBD::generateImgPyramid builds pyramids into a

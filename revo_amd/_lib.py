@@ -125,6 +125,15 @@ def lib():
     L.revo_pipeline_batch.argtypes = [vp, C.c_uint64, vpp]
     L.revo_pipeline_time_tracker.argtypes = [vp, C.c_int]
     L.revo_pipeline_tracker_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
+    L.revo_comm_available.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.revo_comm_unique_id.argtypes = [u8p]
+    L.revo_comm_create.argtypes = [vp, u8p, C.c_int, C.c_int, vpp]
+    L.revo_comm_destroy.argtypes = [vp]
+    L.revo_comm_destroy.restype = None
+    L.revo_comm_world.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.revo_comm_allgather_records.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.revo_pipeline_set_comm.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+    L.revo_pipeline_flush_comm.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 

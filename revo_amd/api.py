@@ -457,10 +457,62 @@ class Pipeline:
     def time_tracker(self, every_n):
         check(_lib.lib().revo_pipeline_time_tracker(self._h, every_n))
 
+    def set_comm(self, comm, every, d_gathered, ring):
+        """revo_pipeline_set_comm: the handle enqueues the all-gather of every window of `every` steps itself, in the
+        after-grid slot of the window's last step; d_gathered: raw device pointer, ring * world * every * n_pairs records."""
+        check(_lib.lib().revo_pipeline_set_comm(self._h, comm._h if comm is not None else None, every, d_gathered, ring))
+        self._comm = comm  # keep it alive as long as it is attached
+
+    def flush_comm(self):
+        """-> (steps of the incomplete last window that were gathered, its slot in d_gathered); (0, slot) if nothing was pending."""
+        n, slot = C.c_int(), C.c_int()
+        check(_lib.lib().revo_pipeline_flush_comm(self._h, C.byref(n), C.byref(slot)))
+        return n.value, slot.value
+
     def tracker_ms(self):
         ms, n = C.c_float(), C.c_int()
         check(_lib.lib().revo_pipeline_tracker_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def rccl_available():
+    """(path, version) of the RCCL library librevo_hip.so binds at run time, or raises RevoError."""
+    buf, ver = C.create_string_buffer(256), C.c_int()
+    check(_lib.lib().revo_comm_available(buf, 256, C.byref(ver)))
+    return buf.value.decode(), ver.value
+
+
+def comm_unique_id():
+    """revo_comm_unique_id (rank 0): 128 bytes to ship to the other ranks."""
+    buf = (C.c_uint8 * 128)()
+    check(_lib.lib().revo_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """revo_comm_*: an RCCL communicator behind the C ABI (one process per GPU).  `uid`: the 128 bytes rank 0 got
+    from comm_unique_id(), shipped to every rank by the caller.  Creation is a collective (ncclCommInitRank)."""
+
+    def __init__(self, cameraPyr, uid, world_size, rank):
+        self._cam = cameraPyr
+        self._h = vp()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        check(_lib.lib().revo_comm_create(cameraPyr._h, buf, int(world_size), int(rank), C.byref(self._h)))
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    def allgather_records(self, d_send, d_recv, n_records, stream=None):
+        check(_lib.lib().revo_comm_allgather_records(self._h, d_send, d_recv, int(n_records), stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().revo_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HostBatchTracker:

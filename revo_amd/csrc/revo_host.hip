@@ -84,6 +84,7 @@ struct FrameSet {
   std::atomic<bool> edt_pending{false};  // set by a batch build, cleared under edt_mu by whoever runs the EDT
   int edt_count = 0;              // keyframes: frames 0, 2, 4, ...
   bool pts_pending = false;       // (REVO_DEFER >= 2) the tile-ordered edge lists of ALL frames were left to the same consumer too
+  bool depth_pending = false;     // ... and the build ran only the gray half of pyrDown: the depth half goes in front of the lists
   bool hyst_pending = false;      // (REVO_DEFER = 3) ... and hysteresis + fill-in: the build stopped behind the Canny NMS
   // whoever ran the deferred EDT recorded this on ITS stream: consumers (and the next build into these planes) on any other
   // stream order themselves behind it (`edt_pending == false` alone says "enqueued somewhere", not "visible here")
@@ -180,6 +181,7 @@ struct revo_batch {
   hipEvent_t ev_trk = nullptr;
   hipStream_t trk_stream = nullptr;
   bool has_trk = false;
+  hipEvent_t tev0 = nullptr, tev1 = nullptr;       // (revo_batch_time_next_grid_) recorded directly around the NEXT tracker grid, then cleared
   const revo_pair_result* last_results = nullptr;  // device records of the last track launch (revo_batch_sync decodes their flags)
   revo_pair_result* h_flags = nullptr;             // pinned scratch for that
 };
@@ -666,9 +668,13 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
   // (the edge lists and the EDT do not depend on each other; running the EDT first -- next to the memory-bound first kernels of
   // the following build instead of its VALU-bound NMS -- was measured equal: profiles/r04_ab_aux_order.txt)
   if (fs->pts_pending) {
-    // ... with the depth half of the pyramid in front of them (nothing on the build stream reads the coarser depth levels or the
-    // validity bits: they feed the edge lists only)
-    for (int l = 1; l < c->geom.n_levels; ++l) launch_pyrdown(c->geom, fs->p, l, fs->B, s, 2);
+    // ... with the depth half of the pyramid in front of them when the build left it out (nothing on the build stream reads the
+    // coarser depth levels or the validity bits: they feed the edge lists only).  Only then: with REVO_SPLIT_DEPTH=0 the build ran
+    // the fused kernel and the depth half must not run a second time.
+    if (fs->depth_pending) {
+      for (int l = 1; l < c->geom.n_levels; ++l) launch_pyrdown(c->geom, fs->p, l, fs->B, s, 2);
+      fs->depth_pending = false;
+    }
     launch_tile_points(c->geom, fs->p, fs->B, s);
     fs->pts_pending = false;
   }
@@ -1343,6 +1349,7 @@ static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
     std::lock_guard<std::mutex> lk(b->fs->edt_mu);
     b->fs->hyst_pending = lvl >= 3;
     b->fs->pts_pending = lvl >= 2;
+    b->fs->depth_pending = batch_splits_depth(b);
     b->fs->edt_pending = true; b->fs->edt_count = b->n_pairs;
   } else {
     launch_tile_points(g, b->fs->p, b->fs->B, s);
@@ -1418,10 +1425,20 @@ extern "C" int revo_batch_track_only(revo_batch* b, const float* h_init_RT, revo
   { int rc2 = run_pending_edt(b->ctx, b->fs, s); if (rc2) return rc2; }   // ... or deferred to this launch
   b->last_results = d_results;
   rc = chained_track_launch(b->ctx->device, b->ctx->knobs.track_depth, s, [&](unsigned* d_resident) {
-    return launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
+    // (live timing, ADVICE r05: the pair sits INSIDE the chain -- behind the waits for older grids, the pose upload and the
+    // resident gate, directly around the grid)
+    if (b->tev0) (void)hipEventRecord(b->tev0, s);
+    const int n_wg = launch_track(b->d_descs, tp, d_results, nullptr, b->n_pairs, b->d_mail, &b->mail_epoch, b->cluster, d_resident, s);
+    if (b->tev1) (void)hipEventRecord(b->tev1, s);
+    b->tev0 = b->tev1 = nullptr;
+    return n_wg;
   });
   if (rc) return rc;
   return batch_mark_tracker(b, s);
+}
+// the next revo_batch_track_only of this batch records ev0 / ev1 (hipEvent_t) directly around its grid
+extern "C" void revo_batch_time_next_grid_(revo_batch* b, void* ev0, void* ev1) {
+  if (b) { b->tev0 = (hipEvent_t)ev0; b->tev1 = (hipEvent_t)ev1; }
 }
 
 // Same as revo_batch_build for raw 16-bit depth (the reference's on-disk format): the conversion
@@ -1718,7 +1735,7 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
   }
   {  // the state a build + prepare leaves behind
     std::lock_guard<std::mutex> lk(fs->edt_mu);
-    fs->edt_pending = false; fs->pts_pending = false; fs->hyst_pending = false;
+    fs->edt_pending = false; fs->pts_pending = false; fs->depth_pending = false; fs->hyst_pending = false;
     HIPCHECK(hipEventRecord(fs->ev_edt, s));
     fs->has_edt = true; fs->edt_stream = s;
   }

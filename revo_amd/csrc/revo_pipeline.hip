@@ -32,6 +32,7 @@ extern "C" void revo_ctx_retain_(revo_ctx*);
 extern "C" void revo_ctx_release_(revo_ctx*);
 extern "C" int revo_ctx_device_(const revo_ctx*);
 extern "C" void revo_set_error_(const char* msg);
+extern "C" void revo_batch_time_next_grid_(revo_batch*, void* ev0, void* ev1);
 
 namespace {
 
@@ -92,7 +93,19 @@ struct revo_pipeline {
   unsigned long long submitted = 0;
   // probe outcome
   int distinct_queues = 0, streams_replaced = 0, probes = 0;
-  std::vector<hipStream_t> discarded;  // streams that aliased: destroyed with the pipeline (destroying them earlier would hand their queue slot to the next one)
+  // every stream this handle ever created, kept or discarded as aliasing, from the moment it exists: destroyed with the
+  // pipeline (destroying an aliasing one earlier would hand its queue slot to the next candidate) -- an error path in between
+  // leaks nothing
+  std::vector<hipStream_t> owned;
+  // the result collective (revo_pipeline_set_comm): windows of `every` steps, `ring` windows in rotation
+  revo_comm* comm = nullptr;
+  int every = 0, ring = 0, world = 1;
+  revo_pair_result* d_send = nullptr;      // [ring][every][n_pairs]: the grids of a window write their records here
+  revo_pair_result* d_gathered = nullptr;  // caller's: [ring][world][every][n_pairs]
+  std::vector<hipEvent_t> ev_step;         // [ring * every]: behind the grid of a window's step (the collective waits for the steps on the other tracker stream)
+  std::vector<hipEvent_t> ev_coll;         // [ring]: behind the collective that read send window w
+  std::vector<char> coll_pending;          // [ring]
+  unsigned long long collectives = 0;
   // live timing of the tracker grid (bench.py's roofline leg): every `time_every`-th submit carries an event pair
   int time_every = 0;
   double timed_ms = 0.0;
@@ -121,6 +134,7 @@ int streams_alias(hipStream_t a, hipStream_t b, unsigned long long* d_buf, unsig
 int pick_streams(revo_pipeline* p, int want, std::vector<hipStream_t>* out) {
   const bool probe = env_int("REVO_PIPE_PROBE", 1, 0, 1) != 0;
   unsigned long long* d_buf = nullptr;
+  struct BufGuard { unsigned long long** p; ~BufGuard() { if (*p) (void)hipFree(*p); } } buf_guard{&d_buf};
   int rate_khz = 0;
   if (probe) {
     PCHECK(hipMalloc((void**)&d_buf, 4 * sizeof(unsigned long long)));
@@ -134,6 +148,7 @@ int pick_streams(revo_pipeline* p, int want, std::vector<hipStream_t>* out) {
     ++tries;
     hipStream_t s = nullptr;
     PCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    p->owned.push_back(s);
     bool bad = false;
     if (probe) {
       // first use of a stream binds it to its hardware queue: touch it before probing
@@ -161,8 +176,6 @@ int pick_streams(revo_pipeline* p, int want, std::vector<hipStream_t>* out) {
                     "queue run one after the other\n", (int)kept.size(), want);
   // not enough distinct queues: fill up with aliasing streams (still correct, only slower) and say so in revo_pipeline_info
   while ((int)kept.size() < want && !aliased.empty()) { kept.push_back(aliased.front()); aliased.erase(aliased.begin()); }
-  p->discarded = aliased;
-  if (d_buf) (void)hipFree(d_buf);
   if (!probe) p->distinct_queues = -1;  // unknown
   *out = kept;
   return REVO_OK;
@@ -204,6 +217,7 @@ extern "C" int revo_pipeline_create(revo_ctx* ctx, int n_pairs, int depth, int h
   // the tracker streams first (the order the measured shape was created in), then build, then auxiliary
   if (depth == 1) {
     PCHECK(hipStreamCreateWithFlags(&p->s_trk[0], hipStreamNonBlocking));
+    p->owned.push_back(p->s_trk[0]);
     p->s_trk[1] = p->s_build = p->s_aux = p->s_trk[0];
     p->ntrk = 1; p->distinct_queues = 1;
   } else {
@@ -248,12 +262,10 @@ extern "C" void revo_pipeline_destroy(revo_pipeline* p) {
     (void)hipFree(sl.d_res);
     if (sl.h_res) (void)hipHostFree(sl.h_res);
   }
-  for (int i = 0; i < 4; ++i) {
-    bool dup = false;
-    for (int j = 0; j < i; ++j) dup = dup || all[j] == all[i];
-    if (all[i] && !dup) (void)hipStreamDestroy(all[i]);
-  }
-  for (hipStream_t s : p->discarded) (void)hipStreamDestroy(s);
+  for (hipEvent_t e : p->ev_step) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_coll) if (e) (void)hipEventDestroy(e);
+  if (p->d_send) (void)hipFree(p->d_send);
+  for (hipStream_t s : p->owned) (void)hipStreamDestroy(s);
   (void)hipGetLastError();
   revo_ctx* c = p->ctx;
   delete p;
@@ -266,6 +278,11 @@ extern "C" int revo_pipeline_submit(revo_pipeline* p, const uint8_t* d_bgr, cons
   if (!p || !d_bgr || !d_depth) return fail(REVO_ERR_INVALID_ARG, "null argument");
   if (depth_kind < 0 || depth_kind > 2) return fail(REVO_ERR_INVALID_ARG, "depth_kind: 0 = f32 borrowed, 1 = f32 copied, 2 = u16 raw");
   std::lock_guard<std::mutex> lk(p->mu);
+  //  without host results, without a communicator and without a caller buffer the records would land in a buffer no
+  // call exposes: refuse instead of losing them silently
+  if (!d_results && !p->host_results && !p->comm)
+    return fail(REVO_ERR_INVALID_ARG, "d_results is NULL and the pipeline neither copies records to the host (host_results) nor gathers them "
+                                      "(revo_pipeline_set_comm): the step's records would be unreachable");
   PCHECK(hipSetDevice(p->device));
   const unsigned long long t = p->submitted;
   Slot& sl = p->slots[t % p->nb];
@@ -292,16 +309,41 @@ extern "C" int revo_pipeline_submit(revo_pipeline* p, const uint8_t* d_bgr, cons
   // what the build left to its first consumer runs on the auxiliary stream, behind the set's "built" event
   if (p->s_aux != p->s_build) { rc = revo_batch_prepare(sl.batch, p->s_aux); if (rc) return rc; }
   revo_pair_result* d_out = d_results ? d_results : sl.d_res;
-  const bool time_it = p->time_every > 0 && ((t + 1) % (unsigned long long)p->time_every) == 0;
-  if (time_it) {
-    // order the tracker stream behind the prepared work first, so that the event pair brackets the grid alone
-    rc = revo_batch_prepare(sl.batch, s_tr);
-    if (rc) return rc;
-    PCHECK(hipEventRecord(sl.t0, s_tr));
+  // with a communicator the grid writes straight into its window of the send buffer (step j of window k -> slot k % ring)
+  const unsigned long long win = p->comm ? t / (unsigned long long)p->every : 0ull;
+  const int wj = p->comm ? (int)(t % (unsigned long long)p->every) : 0, ws = p->comm ? (int)(win % (unsigned long long)p->ring) : 0;
+  if (p->comm) {
+    d_out = p->d_send + ((size_t)ws * p->every + wj) * p->n_pairs;
+    // the collective that read this send window `ring` windows ago may still be in flight on the other tracker stream
+    if (p->coll_pending[ws]) PCHECK(hipStreamWaitEvent(s_tr, p->ev_coll[ws], 0));
   }
+  const bool time_it = p->time_every > 0 && ((t + 1) % (unsigned long long)p->time_every) == 0;
+  // the event pair is recorded inside the tracker chain, directly around the grid: behind the waits for older grids, the
+  // pose upload and the resident gate (recorded here, around the call, it timed gate + waits + grid)
+  if (time_it) revo_batch_time_next_grid_(sl.batch, (void*)sl.t0, (void*)sl.t1);
   rc = revo_batch_track_only(sl.batch, h_init_RT, d_out, s_tr);
-  if (rc) return rc;
-  if (time_it) { PCHECK(hipEventRecord(sl.t1, s_tr)); sl.timed = true; }
+  if (rc) { if (time_it) revo_batch_time_next_grid_(sl.batch, nullptr, nullptr); return rc; }
+  if (time_it) sl.timed = true;
+  if (p->comm) {
+    if (d_results) PCHECK(hipMemcpyAsync(d_results, d_out, sizeof(revo_pair_result) * p->n_pairs, hipMemcpyDeviceToDevice, s_tr));
+    if (wj == 0) p->coll_pending[ws] = 0;  // a new window starts in this slot
+    if (wj + 1 < p->every) {
+      PCHECK(hipEventRecord(p->ev_step[(size_t)ws * p->every + wj], s_tr));
+    } else {
+      // the window is complete with this grid: its earlier steps ran on the other tracker stream (alternating), order them
+      // in front, then ONE all-gather of the window's records in this step's after-grid slot
+      if (p->ntrk > 1)
+        for (int j = 0; j < wj; ++j)
+          if ((int)((t - (unsigned long long)(wj - j)) % (unsigned long long)p->ntrk) != trk)
+            PCHECK(hipStreamWaitEvent(s_tr, p->ev_step[(size_t)ws * p->every + j], 0));
+      rc = revo_comm_allgather_records(p->comm, p->d_send + (size_t)ws * p->every * p->n_pairs,
+                                       p->d_gathered + (size_t)ws * p->world * p->every * p->n_pairs, p->every * p->n_pairs, (void*)s_tr);
+      if (rc) return rc;
+      PCHECK(hipEventRecord(p->ev_coll[ws], s_tr));
+      p->coll_pending[ws] = 1;
+      p->collectives += 1;
+    }
+  }
   if (p->host_results)
     PCHECK(hipMemcpyAsync(sl.h_res, d_out, sizeof(revo_pair_result) * p->n_pairs, hipMemcpyDeviceToHost, s_tr));
   p->submitted = t + 1;
@@ -394,5 +436,70 @@ extern "C" int revo_pipeline_tracker_ms(revo_pipeline* p, float* mean_ms, int* l
   std::lock_guard<std::mutex> lk(p->mu);
   if (mean_ms) *mean_ms = p->timed_n ? (float)(p->timed_ms / p->timed_n) : 0.f;
   if (launches) *launches = p->timed_n;
+  return REVO_OK;
+}
+
+// ---- the result collective inside the pipeline -------------------------------------------------------------
+extern "C" int revo_pipeline_set_comm(revo_pipeline* p, revo_comm* comm, int every, revo_pair_result* d_gathered, int ring) {
+  if (!p) return fail(REVO_ERR_INVALID_ARG, "null pipeline");
+  std::lock_guard<std::mutex> lk(p->mu);
+  PCHECK(hipSetDevice(p->device));
+  if (p->submitted % (unsigned long long)(p->every > 0 ? p->every : 1) != 0)
+    return fail(REVO_ERR_INVALID_ARG, "a window of the current communicator is incomplete: revo_pipeline_flush_comm first");
+  // detach / re-attach only with nothing in flight
+  hipStream_t all[4] = {p->s_build, p->s_aux, p->s_trk[0], p->s_trk[1]};
+  for (int i = 0; i < 4; ++i) PCHECK(hipStreamSynchronize(all[i]));
+  for (hipEvent_t e : p->ev_step) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_coll) if (e) (void)hipEventDestroy(e);
+  p->ev_step.clear(); p->ev_coll.clear(); p->coll_pending.clear();
+  if (p->d_send) { (void)hipFree(p->d_send); p->d_send = nullptr; }
+  p->comm = nullptr; p->every = 0; p->ring = 0; p->world = 1; p->d_gathered = nullptr;
+  if (!comm) return REVO_OK;
+  if (every < 1 || every > 8 || ring < 2 || ring > 16 || !d_gathered)
+    return fail(REVO_ERR_INVALID_ARG, "set_comm: every must be 1..8, ring 2..16, d_gathered non-null");
+  if (p->submitted != 0 && p->submitted % (unsigned long long)every != 0)
+    return fail(REVO_ERR_INVALID_ARG, "set_comm: attach at a multiple of `every` submitted steps");
+  int world = 1, rank = 0;
+  { int rc = revo_comm_world(comm, &world, &rank); if (rc) return rc; }
+  PCHECK(hipMalloc((void**)&p->d_send, sizeof(revo_pair_result) * (size_t)ring * every * p->n_pairs));
+  PCHECK(hipMemset(p->d_send, 0, sizeof(revo_pair_result) * (size_t)ring * every * p->n_pairs));
+  PCHECK(hipStreamSynchronize(nullptr));
+  p->ev_step.assign((size_t)ring * every, nullptr);
+  p->ev_coll.assign((size_t)ring, nullptr);
+  p->coll_pending.assign((size_t)ring, 0);
+  for (hipEvent_t& e : p->ev_step) PCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t& e : p->ev_coll) PCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  p->comm = comm; p->every = every; p->ring = ring; p->world = world; p->d_gathered = d_gathered;
+  return REVO_OK;
+}
+
+// Gathers an INCOMPLETE last window (submitted % every steps; the unused steps of the window carry stale records) in the
+// after-grid slot of the last submitted step.  A collective: every rank calls it at the same point.  *steps_out: how many steps
+// of the window are valid (0: the last window was complete, nothing was enqueued), *slot_out: its slot in d_gathered.
+extern "C" int revo_pipeline_flush_comm(revo_pipeline* p, int* steps_out, int* slot_out) {
+  if (!p) return fail(REVO_ERR_INVALID_ARG, "null pipeline");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (!p->comm) return fail(REVO_ERR_INVALID_ARG, "no communicator attached");
+  PCHECK(hipSetDevice(p->device));
+  const int have = (int)(p->submitted % (unsigned long long)p->every);
+  const unsigned long long win = p->submitted / (unsigned long long)p->every;
+  const int ws = (int)(win % (unsigned long long)p->ring);
+  if (steps_out) *steps_out = have;
+  if (slot_out) *slot_out = ws;
+  if (!have) return REVO_OK;
+  const unsigned long long t_last = p->submitted - 1;
+  const int trk = (int)(t_last % (unsigned long long)p->ntrk);
+  hipStream_t s_tr = p->s_trk[trk];
+  for (int j = 0; j < have; ++j)
+    if ((int)((win * p->every + j) % (unsigned long long)p->ntrk) != trk)
+      PCHECK(hipStreamWaitEvent(s_tr, p->ev_step[(size_t)ws * p->every + j], 0));
+  int rc = revo_comm_allgather_records(p->comm, p->d_send + (size_t)ws * p->every * p->n_pairs,
+                                       p->d_gathered + (size_t)ws * p->world * p->every * p->n_pairs, p->every * p->n_pairs, (void*)s_tr);
+  if (rc) return rc;
+  PCHECK(hipEventRecord(p->ev_coll[ws], s_tr));
+  p->coll_pending[ws] = 1;
+  p->collectives += 1;
+  // the window is closed: the next submit starts a fresh one (the step counter moves to the next multiple of `every`)
+  p->submitted = (win + 1) * (unsigned long long)p->every;
   return REVO_OK;
 }

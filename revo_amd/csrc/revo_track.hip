@@ -60,25 +60,33 @@ enum { MODE_EVAL = 0, MODE_COST = 1, MODE_DONE = 2 };
 enum { PH_FIRST = 0, PH_LM = 1, PH_REFILL = 2, PH_EVAL_ONLY = 3 };
 #define NWAVES (TRACK_THREADS / 64)
 #define KMAX TRACK_KMAX
-#define NVAL TRACK_NVAL          // 32 normal-equation slots (27 used) + 16 error slots (3 per candidate)
-#define ESLOT 32
+#define NVAL TRACK_NVAL          // granules a workgroup publishes per pass: 32 float slots + 8 double slots as two words each
+#define CSLOT 27                 // float slots: 0..26 normal equations (21 + 6), CSLOT + j = good-point count of candidate j
+#define NSUM 40                  // per-wave partials in LDS, all as double: 32 float slots, then 8 double slots (DSLOT below;
+                                 // MODE_COST: slots 0 / 2 = the two costs)
 #define SPIN_LIMIT 400000      // bounded cluster wait (~0.5 s): never hang the GPU
 #define MAX_TOTAL_EVALS 6000  // hang guard; the reference bound is 100 outer iterations x retries
-static_assert(3 * KMAX <= 16, "error slots: 3 per candidate");
+static_assert(CSLOT + KMAX <= 32 && NVAL == 48 && NSUM == 40 && 1 + KMAX <= 8, "slot layout");
 
-struct Cand {  // one pose to evaluate; for LM candidates also what the decision needs when it is consumed
-  float R[9], T[3];
-  float q[4], t[3];    // Sophus::SE3f new_referenceToFrame (optimizer.cpp:266)
-  float incsq, lambda; // inc.dot(inc) and the damping this candidate was solved with
-  int incTry;          // incTry after its increment (optimizer.cpp:263)
+struct Cand {  // one pose to evaluate (R, T: what the evaluating waves read); for LM candidates also what the decision needs
+  float R[9], T[3];    // R column-major; T is also the translation of Sophus::SE3f new_referenceToFrame (optimizer.cpp:266)
+  float q[4];          // its quaternion
+  float incsq;         // inc.dot(inc) (optimizer.cpp:296)
+  float pad[3];
 };
 struct PassCtl { int mode, level, ncand, phase; };
-struct LMState {
+struct SolverState {   // the LM state between passes: one PRIVATE copy per solver wave (they all take the same decisions)
   float q[4], t[3];    // accepted pose (Sophus::SE3f referenceToFrame)
-  float lastErr, last_residual, lambda;
-  int iteration, incTry, flags, total_evals, good, bad;
-  float sumw, sumu;
+  float lastErr;       // == last_residual (optimizer.cpp:276)
+  float lambda;
+  int iteration, incTry, total_evals;
+  float lamc[KMAX];    // dampings of the candidates in flight; candidate j was solved with incTry + 1 + j (optimizer.cpp:263)
+  int flags, good, bad, pad;
 };
+
+// wave-uniform control flow: a condition every lane computes alike, as a scalar the compiler can branch on without exec masks
+#define UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+__device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- small algebra (Eigen/Sophus semantics, float like the reference) -------
 // Eigen's Quaternionf(Matrix3f): four algebraically equivalent branches chosen by the
@@ -140,45 +148,47 @@ __device__ __forceinline__ bool is_orthogonal(const float* R) {  // rotation_mat
 // divisions and the catastrophic cancellation of the closed forms ((1-cos theta)/theta^2 in float loses three
 // digits at theta = 0.01) -- on the serial path of every LM pass this is ~0.5 us.  Sophus' own small-angle
 // branch (theta < 1e-5: Taylor quaternion, V = R) is kept as it is.
+// Every value here is wave-uniform (the solver wave's lanes all hold the same numbers): the branches are scalar (UNI).
+// V = I + ca Omega + cb Omega^2 is written out with the structural zeros of Omega folded by hand (round 6): the products
+// with 0 and the sums with +-0 of the generic 3x3 products return their other operand exactly, so every entry keeps the
+// value the matrix form gives it (only the SIGN of an exact zero can differ); 27 operations instead of 81 on the
+// serial path of every pass.
 __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, const float* t, float* qo, float* to) {
   const float ox = a[3], oy = a[4], oz = a[5];
   const float t2 = ox * ox + oy * oy + oz * oz;
   float imag, real, ca, cb;
-  if (t2 < 0.25f) {
+  if (UNI(t2 < 0.25f)) {
     imag = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 185794560.0f, -1.0f / 645120.0f), 1.0f / 3840.0f), -1.0f / 48.0f), 0.5f);
     real = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, -1.0f / 3715891200.0f, 1.0f / 10321920.0f), -1.0f / 46080.0f), 1.0f / 384.0f), -0.125f), 1.0f);
     ca = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 3628800.0f, -1.0f / 40320.0f), 1.0f / 720.0f), -1.0f / 24.0f), 0.5f);
     cb = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 39916800.0f, -1.0f / 362880.0f), 1.0f / 5040.0f), -1.0f / 120.0f), 1.0f / 6.0f);
-  } else {  // a diverging step
+  } else {  // a diverging step (also NaN)
     const float theta = sqrtf(t2), h = 0.5f * theta;
     imag = __fdiv_rn(sinf(h), theta);
     real = cosf(h);
     ca = __fdiv_rn(1.0f - cosf(theta), t2);
     cb = __fdiv_rn(theta - sinf(theta), t2 * theta);
   }
-  const bool tiny = t2 < 1e-10f;  // theta < Constants<float>::epsilon() = 1e-5 (common.hpp:150-158)
-  float V[9];  // row-major 3x3
-  const float O[9] = {0.f, -oz, oy, oz, 0.f, -ox, -oy, ox, 0.f};
   const float qe[4] = {real, imag * ox, imag * oy, imag * oz};
-  if (tiny) {
-    float Rm[9];
-    quat_to_R(qe, Rm);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) V[r * 3 + c] = Rm[c * 3 + r];
-  } else {
-    float O2[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) V[i] = (((i % 4) == 0 ? 1.0f : 0.0f) + ca * O[i]) + cb * O2[i];
-  }
   float te[3];
+  if (UNI(t2 < 1e-10f)) {  // theta < Constants<float>::epsilon() = 1e-5 (common.hpp:150-158): V = matrix(qe)
+    float Rm[9];
+    quat_to_R(qe, Rm);  // column-major: V[r][c] = Rm[c * 3 + r]
 #pragma unroll
-  for (int r = 0; r < 3; ++r) te[r] = V[r * 3] * a[0] + V[r * 3 + 1] * a[1] + V[r * 3 + 2] * a[2];
+    for (int r = 0; r < 3; ++r) te[r] = Rm[r] * a[0] + Rm[3 + r] * a[1] + Rm[6 + r] * a[2];
+  } else {
+    // Omega = [0 -oz oy; oz 0 -ox; -oy ox 0];  Omega^2: diagonal -(oy^2 + oz^2) ..., off-diagonal ox oy ...
+    const float xx = ox * ox, yy = oy * oy, zz = oz * oz, xy = oy * ox, xz = oz * ox, yz = oz * oy;
+    const float d0 = (-zz) + (-yy), d1 = (-zz) + (-xx), d2 = (-yy) + (-xx);
+    const float V00 = 1.0f + cb * d0, V11 = 1.0f + cb * d1, V22 = 1.0f + cb * d2;
+    const float px = ca * ox, py = ca * oy, pz = ca * oz, sxy = cb * xy, sxz = cb * xz, syz = cb * yz;
+    const float V01 = (-pz) + sxy, V10 = pz + sxy;
+    const float V02 = py + sxz, V20 = (-py) + sxz;
+    const float V12 = (-px) + syz, V21 = px + syz;
+    te[0] = V00 * a[0] + V01 * a[1] + V02 * a[2];
+    te[1] = V10 * a[0] + V11 * a[1] + V12 * a[2];
+    te[2] = V20 * a[0] + V21 * a[1] + V22 * a[2];
+  }
   // translation: te + qe (x) t   (Eigen _transformVector)
   float uv[3] = {qe[2] * t[2] - qe[3] * t[1], qe[3] * t[0] - qe[1] * t[2], qe[1] * t[1] - qe[2] * t[0]};
   uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
@@ -191,7 +201,7 @@ __device__ __forceinline__ void se3_exp_mul(const float* a, const float* q, cons
   float y = qe[0] * q[2] + qe[2] * q[0] + qe[3] * q[1] - qe[1] * q[3];
   float z = qe[0] * q[3] + qe[3] * q[0] + qe[1] * q[2] - qe[2] * q[1];
   const float sn = w * w + x * x + y * y + z * z;
-  if (sn != 1.0f) {
+  if (UNI(sn != 1.0f)) {
     const float s = __fdiv_rn(2.0f, 1.0f + sn);
     w *= s; x *= s; y *= s; z *= s;
   }
@@ -232,13 +242,18 @@ __device__ __forceinline__ float rl(float v, int src) {  // wave-uniform copy of
 // abv: lane k (< 27) of the calling wave holds entry k of the normalised normal equations (21 upper-triangle
 // entries of A, then 6 of the rhs).  Must be called by all 64 lanes of a wave (lanes >= 6 shadow row 5); x is
 // wave-uniform.
-__device__ __forceinline__ void solve6_ldlt(float abv, float lambda, float* x, int lane) {
+__device__ __forceinline__ float rl_dyn(float v, int src) {  // src: wave-uniform, not a constant
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src));
+}
+__device__ __forceinline__ void solve6_ldlt(float abv_in, float lambda, float* x, int lane) {
   const float damp = 1.0f + lambda;  // A(i,i) *= 1 + LM_lambda, optimizer.cpp:261
+  // the damped system, entry for entry: lanes AIDX(i,i) = 0, 6, 11, 15, 18, 20 hold the diagonal
+  const float abv = (lane < 21 && ((0x148841u >> lane) & 1u)) ? abv_in * damp : abv_in;
   // transpositions on the damped diagonal: big = first maximum of |diag| among positions >= k
   float dv[6];
   int idx[6];  // idx[i] = original row/column at position i of P A P^T
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { dv[i] = fabsf(rl(abv, AIDX(i, i)) * damp); idx[i] = i; }
+  for (int i = 0; i < 6; ++i) { dv[i] = fabsf(rl(abv, AIDX(i, i))); idx[i] = i; }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     int big = k;
@@ -266,29 +281,27 @@ __device__ __forceinline__ void solve6_ldlt(float abv, float lambda, float* x, i
   for (int c = 0; c < 6; ++c) {
     const int oc = idx[c];
     const int lo = myorig < oc ? myorig : oc, hi = myorig < oc ? oc : myorig;
-    float v = __shfl(abv, AIDX(lo, hi));
-    if (lo == hi) v = v * damp;
-    m[c] = v;
+    m[c] = __shfl(abv, hi + ((lo * (11 - lo)) >> 1));  // AIDX(lo, hi)
   }
   float v = __shfl(abv, 21 + myorig);  // m_transpositions * rhs
-  float D[6];
+  float D[6], w[6];  // w[c] = L(:,c) * D[c]: lane k holds temp[c] = D[c] * L(k,c) of step k (the same product, commuted)
+  float mydiag = 0.0f;
   bool stop = false;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     if (k > 0 && !stop) {
       float a2 = 0.0f;
 #pragma unroll
-      for (int c = 0; c < k; ++c) {
-        const float tc = D[c] * rl(m[c], k);  // temp = D(0..k) .* A10^T
-        a2 = a2 + m[c] * tc;
-      }
+      for (int c = 0; c < k; ++c) a2 = a2 + m[c] * rl(w[c], k);  // temp = D(0..k) .* A10^T
       if (row >= k) m[k] = m[k] - a2;         // A(k,k) -= A10 temp ; A21 -= A20 temp
     }
     const float akk = rl(m[k], k);
     D[k] = akk;
+    mydiag = (row == k) ? akk : mydiag;
     const bool valid = fabsf(akk) > 0.0f;
     if (k == 0 && !valid) stop = true;        // the whole diagonal is zero: Eigen leaves the matrix as it is
     if (!stop && valid && row > k) m[k] = __fdiv_rn(m[k], akk);
+    w[k] = m[k] * akk;
   }
   // L y = P b (j ascending per row)
 #pragma unroll
@@ -297,28 +310,21 @@ __device__ __forceinline__ void solve6_ldlt(float abv, float lambda, float* x, i
     if (row > j) v = v - m[j] * yj;
   }
   // pseudo-inverse of D (tolerance = 1 / highest())
-  float mydiag = D[0];
-#pragma unroll
-  for (int i = 1; i < 6; ++i) mydiag = (row == i) ? D[i] : mydiag;
   v = (fabsf(mydiag) > 1.17549435e-38f) ? __fdiv_rn(v, mydiag) : 0.0f;
-  // L^T z = y: z_i = y_i - sum_{j>i} L[j][i] z_j, j ascending
-  float zs[6];
+  // L^T z = y: z_i = y_i - sum_{j>i} L[j][i] z_j, j ascending; lane i ends with z_i
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     const float term = m[i] * v;  // lane j > i: L[j][i] * z_j (z_j is final on those lanes)
     float acc = rl(v, i);
 #pragma unroll
     for (int j = i + 1; j < 6; ++j) acc = acc - rl(term, j);
-    zs[i] = acc;
     if (row == i) v = acc;
   }
-  // P^T z
+  // P^T z: x[o] = z at the position that holds original index o
 #pragma unroll
   for (int o = 0; o < 6; ++o) {
-    float xo = zs[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) xo = (idx[i] == o) ? zs[i] : xo;
-    x[o] = xo;
+    const unsigned long long at = __builtin_amdgcn_ballot_w64(lane < 6 && myorig == o);
+    x[o] = rl_dyn(v, (int)__builtin_ctzll(at));
   }
 }
 
@@ -361,53 +367,94 @@ __device__ __forceinline__ void reduce32(float* v, int lane) {
 __device__ __forceinline__ int idx32(int lane) {
   return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
 }
-// 16 values: lane L ends with the wave total of value idx16(L) in v[0]
-__device__ __forceinline__ void reduce16(float* v, int lane) {
-  butterfly_step<8, 1>(v, lane);
-  butterfly_step<4, 2>(v, lane);
-  butterfly_step<2, 4>(v, lane);
-  butterfly_step<1, 8>(v, lane);
-  v[0] += lane_xor<16>(v[0]);
-  v[0] += lane_xor<32>(v[0]);
+// 8 DOUBLE values (the candidates' error sums): lane L ends with the wave total of value idx8(L) in v[0].  Same tree as
+// above; a double crosses lanes as its two words.
+template <int MASK>
+__device__ __forceinline__ double lane_xor_d(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __float_as_uint(lane_xor<MASK>(__uint_as_float((unsigned)u)));
+  const unsigned hi = __float_as_uint(lane_xor<MASK>(__uint_as_float((unsigned)(u >> 32))));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __forceinline__ int idx16(int lane) {
-  return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+template <int HALF, int MASK>
+__device__ __forceinline__ void butterfly_step_d(double* v, int lane) {
+  const bool up = (lane & MASK) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const double send = up ? v[i] : v[HALF + i];
+    const double keep = up ? v[HALF + i] : v[i];
+    v[i] = keep + lane_xor_d<MASK>(send);
+  }
 }
+__device__ __forceinline__ void reduce8d(double* v, int lane) {
+  butterfly_step_d<4, 1>(v, lane);
+  butterfly_step_d<2, 2>(v, lane);
+  butterfly_step_d<1, 4>(v, lane);
+  v[0] += lane_xor_d<8>(v[0]);
+  v[0] += lane_xor_d<16>(v[0]);
+  v[0] += lane_xor_d<32>(v[0]);
+}
+__device__ __forceinline__ int idx8(int lane) { return ((lane & 1) << 2) | (lane & 2) | ((lane & 4) >> 2); }
 
-// ---- cluster all-gather of the NVAL per-workgroup partials -------------------------
+// ---- cluster all-gather of the per-workgroup partials -------------------------
 typedef unsigned long long u64;
-// mail layout per pair: [2 (epoch parity)][cluster][NVAL] granules of {epoch<<32 | float bits}
-__device__ __forceinline__ void cluster_publish(u64* __restrict__ mail_pair, int cluster, int member, unsigned epoch, float mine,
+// mail layout per pair: [2 (epoch parity)][cluster][NVAL] granules of {epoch << 32 | 32 payload bits}.  Granules 0..31 carry
+// the float slots (the workgroup's double sum rounded to float), granules 32 + 2k / 33 + 2k the low / high word of double
+// slot k (the candidates' error sums travel unrounded).
+// tot: lane v < 32 holds float slot v, lanes 32 + 2k and 33 + 2k both hold double slot k
+__device__ __forceinline__ void cluster_publish(u64* __restrict__ mail_pair, int cluster, int member, unsigned epoch, double tot,
                                                 int lane) {
   u64* slot = mail_pair + (size_t)(epoch & 1u) * cluster * NVAL;
+  const u64 bits = (u64)__double_as_longlong(tot);
+  const unsigned word = lane < 32 ? __float_as_uint((float)tot) : ((lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits);
   if (lane < NVAL)
-    __hip_atomic_store(&slot[member * NVAL + lane], ((u64)epoch << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot[member * NVAL + lane], ((u64)epoch << 32) | (u64)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // every member granule in flight at once (a rolled loop would wait for each load before issuing the next:
-// `cluster` serial L2 round trips per poll); MAXC bounds the unrolled sweep
-template <int MAXC>
+// `cluster` serial L2 round trips per poll).  The sums are formed once, after the last granule has arrived.
+// NC = the cluster size as a compile-time constant for the shapes the library picks (no per-member `j < cluster` predicate:
+// with the generic sweep those were 56 loop-invariant conditions, hoisted in front of the pass loop as exec-mask SGPR pairs and
+// spilled to VGPR lanes -- two v_readlane on the serial path for every one of them); NC = 0: any size up to TRACK_MAX_CLUSTER,
+// the members in order behind scalar branches.
+template <int NC>
 __device__ __forceinline__ bool cluster_poll(const u64* __restrict__ slot, int cluster, unsigned epoch, int lane, double* tot_out) {
+  const bool isd = lane >= 32, odd = (lane & 1) != 0;
+  const int my = lane < NVAL ? lane : 0;
   double tot = 0.0;
-  for (unsigned spins = 0;; ++spins) {
-    bool all = true;
-    tot = 0.0;
-    if (lane < NVAL) {
-      u64 g[MAXC];
+  if (NC > 0) {
+    u64 g[NC > 0 ? NC : 1];
+    for (unsigned spins = 0;; ++spins) {
+      bool all = true;
 #pragma unroll
-      for (int j = 0; j < MAXC; ++j)
-        g[j] = (j < cluster) ? __hip_atomic_load(&slot[j * NVAL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      for (int j = 0; j < NC; ++j) g[j] = __hip_atomic_load(&slot[j * NVAL + my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int j = 0; j < MAXC; ++j) {
-        if (j < cluster) {
-          all = all && ((unsigned)(g[j] >> 32) == epoch);
-          tot += (double)__uint_as_float((unsigned)g[j]);  // fixed order j = 0..cluster-1: same bits in every member
-        }
-      }
+      for (int j = 0; j < NC; ++j) all = all && ((unsigned)(g[j] >> 32) == epoch);
+      if (__all(all)) break;
+      if (spins > SPIN_LIMIT) return false;
+      __builtin_amdgcn_s_sleep(1);
     }
-    if (__all(all)) break;
-    if (spins > SPIN_LIMIT) return false;
-    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {  // fixed order j = 0..cluster-1: same bits in every member
+      const unsigned wd = (unsigned)g[j];
+      const unsigned pw = __float_as_uint(lane_xor<1>(__uint_as_float(wd)));  // the other word of the pair
+      const double dd = __longlong_as_double((long long)(((u64)(odd ? wd : pw) << 32) | (u64)(odd ? pw : wd)));
+      tot += isd ? dd : (double)__uint_as_float(wd);
+    }
+  } else {  // any other size: member by member (a granule that carries the epoch stays as it is until everybody has gathered it)
+    for (unsigned spins = 0;; ++spins) {
+      bool all = true;
+      for (int j = 0; j < cluster; ++j)
+        all = all && ((unsigned)(__hip_atomic_load(&slot[j * NVAL + my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == epoch);
+      if (__all(all)) break;
+      if (spins > SPIN_LIMIT) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    for (int j = 0; j < cluster; ++j) {
+      const unsigned wd = (unsigned)__hip_atomic_load(&slot[j * NVAL + my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned pw = __float_as_uint(lane_xor<1>(__uint_as_float(wd)));
+      const double dd = __longlong_as_double((long long)(((u64)(odd ? wd : pw) << 32) | (u64)(odd ? pw : wd)));
+      tot += isd ? dd : (double)__uint_as_float(wd);
+    }
   }
   *tot_out = tot;
   return true;
@@ -415,9 +462,16 @@ __device__ __forceinline__ bool cluster_poll(const u64* __restrict__ slot, int c
 __device__ __forceinline__ bool cluster_gather(const u64* __restrict__ mail_pair, int cluster, unsigned epoch, int lane,
                                                double* tot_out) {
   const u64* slot = mail_pair + (size_t)(epoch & 1u) * cluster * NVAL;
-  if (cluster <= 8) return cluster_poll<8>(slot, cluster, epoch, lane, tot_out);
-  if (cluster <= 16) return cluster_poll<16>(slot, cluster, epoch, lane, tot_out);
-  return cluster_poll<TRACK_MAX_CLUSTER>(slot, cluster, epoch, lane, tot_out);
+  switch (cluster) {  // wave-uniform (a kernel argument)
+    case 2: return cluster_poll<2>(slot, cluster, epoch, lane, tot_out);
+    case 3: return cluster_poll<3>(slot, cluster, epoch, lane, tot_out);
+    case 4: return cluster_poll<4>(slot, cluster, epoch, lane, tot_out);
+    case 6: return cluster_poll<6>(slot, cluster, epoch, lane, tot_out);
+    case 8: return cluster_poll<8>(slot, cluster, epoch, lane, tot_out);
+    case 16: return cluster_poll<16>(slot, cluster, epoch, lane, tot_out);
+    case 32: return cluster_poll<32>(slot, cluster, epoch, lane, tot_out);
+    default: return cluster_poll<0>(slot, cluster, epoch, lane, tot_out);
+  }
 }
 
 // explicit global address space: the pointers come out of the descriptor (generic), and
@@ -470,19 +524,27 @@ __device__ __forceinline__ PtState project_point(const f4v p, const float* R, co
   return s;
 }
 
-// the candidate's error terms: sum w r^2 (fma), sum r^2, good count -- identical arithmetic in the full and the
-// error-only evaluation, so a pose has ONE error whichever way it was evaluated
-__device__ __forceinline__ void accumulate_error(float res, float wr, bool good, float* e) {
+// The candidate's error terms.  The LM's accept / stop decisions compare exactly these sums (optimizer.cpp:129-133,273-278:
+// `error < lastErr`, `error / lastErr > 0.999`), so they are the one place where the ORDER of a float sum would show: the
+// per-point terms are the reference's float values (w_r * res_2 rounded to float, res_2), and the sums are carried in DOUBLE from
+// the first addition on -- per thread, through the butterflies, LDS and the cluster exchange -- and rounded to float once, like the
+// reference's accumulator read at the end (~1e-16 relative whatever the order, the cluster size or the speculation depth: a pose
+// has ONE error however it was evaluated).  The good-point count rides in the float butterfly (exact: < 2^24).
+// Double slots of a pass: 0 = sum w r^2 of candidate 0, 1 = its sum r^2 (ResidualInfo::sumErrorUnweighted: reported, never
+// compared), 1 + j = sum w r^2 of the error-only retry j (j = 1..KMAX-1; nothing reads a retry's unweighted sum).
+#define DSLOT(j) ((j) == 0 ? 0 : 1 + (j))
+template <bool WITH_UNWEIGHTED>
+__device__ __forceinline__ void accumulate_error(float res, float wr, bool good, double* ed, float* cnt) {
   const float r2 = res * res;
-  e[0] = fmaf(wr, r2, e[0]);
-  e[1] += r2;
-  e[2] += good ? 1.0f : 0.0f;
+  ed[0] += (double)(wr * r2);
+  if (WITH_UNWEIGHTED) ed[1] += (double)r2;
+  *cnt += good ? 1.0f : 0.0f;
 }
 
 // calcErrorAndBuffers' interpolation + filter + Huber (optimizer.cpp:106-133, optimizer.h:156-185)
 // fused with calculateWarpUpdate's Jacobian (optimizer.cpp:218-228) and LGS6::update.
-__device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch& q, float fx, float fy, float ed, bool filt,
-                                                 float huber, float* acc, float* e) {
+__device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch& q, float fx, float fy, float edist, bool filt,
+                                                 float huber, float* acc, double* ed) {
   // the reference's table entries at the four corners: (0.5(prev-next), 0.5(up-down), dt)
   const float gx00 = 0.5f * (q.b0 - q.b2), gy00 = 0.5f * (q.a0 - q.c1), d00 = q.b1;
   const float gx10 = 0.5f * (q.b1 - q.b3), gy10 = 0.5f * (q.a1 - q.c2), d10 = q.b2;
@@ -493,7 +555,7 @@ __device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch
   float r0 = ((w11 * gx11 + w01 * gx01) + w10 * gx10) + w00 * gx00;
   float r1 = ((w11 * gy11 + w01 * gy01) + w10 * gy10) + w00 * gy00;
   float res = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
-  const bool good = s.valid && !(res > ed && filt);  // optimizer.cpp:108
+  const bool good = s.valid && !(res > edist && filt);  // optimizer.cpp:108
   if (!good) { r0 = 0.0f; r1 = 0.0f; res = 0.0f; }
   const float wr = (res <= huber) ? 1.0f : revo_div(huber, res);
   const float gx = fx * r0, gy = fy * r1;
@@ -518,14 +580,14 @@ __device__ __forceinline__ void accumulate_point(const PtState& s, const DtPatch
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) acc[21 + a] = fmaf(wv[a], res, acc[21 + a]);
-  accumulate_error(res, wr, good, e);
+  accumulate_error<true>(res, wr, good, ed, acc + CSLOT);
 }
 
-__device__ __forceinline__ void full_point(const f4v p, gf32p dtm, const float* R, const float* T, const Cam& c, float ed,
-                                           bool filt, float huber, float* acc, float* e) {
+__device__ __forceinline__ void full_point(const f4v p, gf32p dtm, const float* R, const float* T, const Cam& c, float edist,
+                                           bool filt, float huber, float* acc, double* ed) {
   const PtState s = project_point(p, R, T, c, true);
   const DtPatch q = load_patch(dtm, c.w, s.ix, s.iy);
-  accumulate_point(s, q, c.fx, c.fy, ed, filt, huber, acc, e);
+  accumulate_point(s, q, c.fx, c.fy, edist, filt, huber, acc, ed);
 }
 
 // TrackerNew::evalCostFunction's per-point term, tracker.cpp:371-389
@@ -563,44 +625,6 @@ __device__ __forceinline__ void load_pose(const Cand& c, float* R, float* T) {
   for (int i = 0; i < 3; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.T[i])));
 }
 
-// NE error-only candidates of one point, interleaved: all projections, then all 4*NE corner loads, then the
-// arithmetic -- the three L2 round trips overlap instead of queueing behind one another
-template <int NE>
-__device__ __forceinline__ void error_points(const f4v p, gf32p dtm, const float (*R)[9], const float (*T)[3], const Cam& c,
-                                             float ed, bool filt, float huber, float* e) {
-  PtState s[NE];
-  float d00[NE], d10[NE], d01[NE], d11[NE];
-#pragma unroll
-  for (int j = 0; j < NE; ++j) s[j] = project_point(p, R[j], T[j], c, true);
-#pragma unroll
-  for (int j = 0; j < NE; ++j) {
-    gf32p q = dtm + s[j].iy * c.w + s[j].ix;
-    d00[j] = q[0]; d10[j] = q[1]; d01[j] = q[c.w]; d11[j] = q[c.w + 1];
-  }
-#pragma unroll
-  for (int j = 0; j < NE; ++j) {
-    const float dxdy = s[j].dx * s[j].dy;
-    const float w11 = dxdy, w01 = s[j].dy - dxdy, w10 = s[j].dx - dxdy, w00 = ((1.0f - s[j].dx) - s[j].dy) + dxdy;
-    float res = ((w11 * d11[j] + w01 * d01[j]) + w10 * d10[j]) + w00 * d00[j];
-    const bool good = s[j].valid && !(res > ed && filt);
-    if (!good) res = 0.0f;
-    const float wr = (res <= huber) ? 1.0f : revo_div(huber, res);
-    accumulate_error(res, wr, good, e + 3 * j);
-  }
-}
-
-template <int NE>
-__device__ __forceinline__ void error_block(const Cand* cand, const f4v* preg, gf4p pts, int first, int stride, int N, gf32p dtm,
-                                            const Cam& cam, float ed, bool filt, float huber, float* e) {
-  float R[NE][9], T[NE][3];
-#pragma unroll
-  for (int j = 0; j < NE; ++j) load_pose(cand[1 + j], R[j], T[j]);
-#pragma unroll
-  for (int k = 0; k < TRACK_MAXP; ++k)
-    if (first + k * stride < N) error_points<NE>(preg[k], dtm, R, T, cam, ed, filt, huber, e + 3);
-  for (int i = first + TRACK_MAXP * stride; i < N; i += stride) error_points<NE>(pts[i], dtm, R, T, cam, ed, filt, huber, e + 3);
-}
-
 // Candidate 0 in full and NE error-only retries of the SAME point in one go.  A retry is a shorter step from the same pose
 // (optimizer.cpp:291-304: same normal equations, larger damping); near convergence -- where the rejections are -- it lands on
 // candidate 0's pixel or a direct neighbour, and then its four DT samples are already in the 12-sample patch: they are
@@ -609,8 +633,8 @@ __device__ __forceinline__ void error_block(const Cand* cand, const f4v* preg, g
 // values from the same addresses, same accumulation order per candidate: the sums do not change by a bit.
 template <int NE>
 __device__ __forceinline__ void fused_point(const f4v p, gf32p dtm, const float* R0, const float* T0, const float (*R)[9],
-                                            const float (*T)[3], const Cam& c, float ed, bool filt, float huber, float* acc,
-                                            float* e) {
+                                            const float (*T)[3], const Cam& c, float edist, bool filt, float huber, float* acc,
+                                            double* ed) {
   const PtState s0 = project_point(p, R0, T0, c, true);
   PtState s[NE];
 #pragma unroll
@@ -630,7 +654,7 @@ __device__ __forceinline__ void fused_point(const f4v p, gf32p dtm, const float*
       g00[j] = t[0]; g10[j] = t[1]; g01[j] = t[c.w]; g11[j] = t[c.w + 1];
     }
   }
-  accumulate_point(s0, q, c.fx, c.fy, ed, filt, huber, acc, e);
+  accumulate_point(s0, q, c.fx, c.fy, edist, filt, huber, acc, ed);
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
     float d00 = g00[j], d10 = g10[j], d01 = g01[j], d11 = g11[j];
@@ -645,24 +669,24 @@ __device__ __forceinline__ void fused_point(const f4v p, gf32p dtm, const float*
     const float dxdy = s[j].dx * s[j].dy;
     const float w11 = dxdy, w01 = s[j].dy - dxdy, w10 = s[j].dx - dxdy, w00 = ((1.0f - s[j].dx) - s[j].dy) + dxdy;
     float res = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
-    const bool good = s[j].valid && !(res > ed && filt);
+    const bool good = s[j].valid && !(res > edist && filt);
     if (!good) res = 0.0f;
     const float wr = (res <= huber) ? 1.0f : revo_div(huber, res);
-    accumulate_error(res, wr, good, e + 3 + 3 * j);
+    accumulate_error<false>(res, wr, good, ed + 2 + j, acc + CSLOT + 1 + j);
   }
 }
 
 template <int NE>
 __device__ __forceinline__ void fused_block(const Cand* cand, const f4v* preg, gf4p pts, int first, int stride, int N, gf32p dtm,
-                                            const Cam& cam, float ed, bool filt, float huber, float* acc, float* e) {
+                                            const Cam& cam, float edist, bool filt, float huber, float* acc, double* ed) {
   float R0[9], T0[3], R[NE][9], T[NE][3];
   load_pose(cand[0], R0, T0);
 #pragma unroll
   for (int j = 0; j < NE; ++j) load_pose(cand[1 + j], R[j], T[j]);
 #pragma unroll
   for (int k = 0; k < TRACK_MAXP; ++k)
-    if (first + k * stride < N) fused_point<NE>(preg[k], dtm, R0, T0, R, T, cam, ed, filt, huber, acc, e);
-  for (int i = first + TRACK_MAXP * stride; i < N; i += stride) fused_point<NE>(pts[i], dtm, R0, T0, R, T, cam, ed, filt, huber, acc, e);
+    if (first + k * stride < N) fused_point<NE>(preg[k], dtm, R0, T0, R, T, cam, edist, filt, huber, acc, ed);
+  for (int i = first + TRACK_MAXP * stride; i < N; i += stride) fused_point<NE>(pts[i], dtm, R0, T0, R, T, cam, edist, filt, huber, acc, ed);
 }
 
 // ---- the kernel ---------------------------------------------------------------
@@ -674,6 +698,12 @@ __device__ __forceinline__ void fused_block(const Cand* cand, const f4v* preg, g
 // One PASS = evaluate the candidates of s_pass/s_cand (all waves) -> barrier -> the kspec "solver" waves each
 // get the totals (LDS sums of the workgroup; through the mailbox when the level is split over the cluster),
 // take the LM decision redundantly and each solve + exponentiate ONE candidate of the next pass -> barrier.
+//
+// The decision (round 6).  Every solver wave keeps its OWN copy of the LM state in LDS (SolverState: all of them take the same
+// decision from the same totals, so the copies never differ, nobody waits for anybody and nothing is double-buffered); its
+// conditions are wave-uniform scalars (UNI / readfirstlane), so the accept / reject ladder of optimizer.cpp:258-304 is scalar
+// branches over a dozen values instead of exec-masked code that copies two 19-word states and a pose through every arm; what a
+// pass hands to the next one (candidate poses, the single pose of a refill / level entry) is written to LDS where it is produced.
 template <bool ONE>
 __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDesc one, const PairDesc* __restrict__ descs,
                                                                    TrackParams prm, revo_pair_result* __restrict__ out,
@@ -683,8 +713,8 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
                                                                    unsigned* resident) {
   __shared__ Cand s_cand[2][KMAX];
   __shared__ PassCtl s_pass[2];
-  __shared__ LMState s_st[2];
-  __shared__ float s_part[NWAVES][NVAL];
+  __shared__ SolverState s_sv[KMAX];
+  __shared__ double s_part[NWAVES][NSUM];
   __shared__ int s_evals[REVO_L];  // residual evaluations per level, in the reference's count (wave 0 / lane 0 only)
 #ifdef REVO_TRACK_PROFILE
   // [12 + l]: cycles spent in level l, [12 + L + l]: its passes, [12 + 2L + l]: evaluation, [12 + 3L + l]: barrier + sums +
@@ -705,7 +735,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   if (pair >= n_pairs) return;
   const PairDesc& d = ONE ? one : descs[pair];
   u64* mail_pair = mail + (size_t)pair * 2 * cluster * NVAL;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, lane_inv = lane, wave = rfl_i(tid >> 6);
   int kmax = 1;  // solver waves: the deepest speculation of any level
 #pragma unroll
   for (int i = 0; i < REVO_L; ++i) kmax = prm.kspec[i] > kmax ? prm.kspec[i] : kmax;
@@ -720,7 +750,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   for (int i = 0; i < REVO_L; ++i) Nl[i] = d.npts[i];
   float abv = 0.0f;  // solver waves: lane k < 27 keeps entry k of the accepted A/n (21) and (sum w r v)/n (6)
 
-  if (wave == 0) {  // ---- pass 0
+  if (wave < kmax) {  // ---- pass 0: every solver wave sets up its own copy of the LM state
     float R0[9], T0[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R0[i] = d.R[i];
@@ -734,39 +764,43 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
       pc.phase = PH_EVAL_ONLY;
     } else if (prm.check_init) {  // tracker.cpp:314 runs BEFORE Sophus::SE3f(R,T) (optimizer.cpp:241)
       pc.mode = MODE_COST; pc.level = prm.pyr_min_lvl; pc.ncand = 2;
-    } else if (!is_orthogonal(R0)) {  // Sophus::SE3f(R,T) would abort
+    } else if (!UNI(is_orthogonal(R0))) {  // Sophus::SE3f(R,T) would abort
       flags = 2;
       pc.mode = MODE_DONE;
     }
     if (lane == 0) {
-      LMState& s = s_st[0];
+      SolverState& s = s_sv[wave];
 #pragma unroll
       for (int i = 0; i < 4; ++i) s.q[i] = q0[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) s.t[i] = T0[i];
-      s.lastErr = s.last_residual = __builtin_nanf("");
+      s.lastErr = __builtin_nanf("");
       s.lambda = 0.f;
       s.iteration = 0; s.incTry = 0; s.flags = flags; s.total_evals = 0;
-      s.good = 0; s.bad = 0; s.sumw = 0.f; s.sumu = 0.f;
+      s.good = 0; s.bad = 0;
 #pragma unroll
-      for (int i = 0; i < REVO_L; ++i) s_evals[i] = 0;
-      Cand& c0 = s_cand[0][0];
-      Cand& c1 = s_cand[0][1];
-      if (pc.mode == MODE_COST) {  // candidate 0 = identity, candidate 1 = the given initialisation (tracker.cpp:272-273)
+      for (int i = 0; i < KMAX; ++i) s.lamc[i] = 0.f;
+      if (wave == 0) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { c0.R[i] = (i % 4 == 0) ? 1.0f : 0.0f; c1.R[i] = R0[i]; }
+        for (int i = 0; i < REVO_L; ++i) s_evals[i] = 0;
+        Cand& c0 = s_cand[0][0];
+        Cand& c1 = s_cand[0][1];
+        if (pc.mode == MODE_COST) {  // candidate 0 = identity, candidate 1 = the given initialisation (tracker.cpp:272-273)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { c0.T[i] = 0.0f; c1.T[i] = T0[i]; }
-      } else {
+          for (int i = 0; i < 9; ++i) { c0.R[i] = (i % 4 == 0) ? 1.0f : 0.0f; c1.R[i] = R0[i]; }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) c0.R[i] = R0[i];
+          for (int i = 0; i < 3; ++i) { c0.T[i] = 0.0f; c1.T[i] = T0[i]; }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) c0.T[i] = T0[i];
-      }
-      s_pass[0] = pc;
+          for (int i = 0; i < 9; ++i) c0.R[i] = R0[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) c0.T[i] = T0[i];
+        }
+        s_pass[0] = pc;
 #ifdef REVO_TRACK_PROFILE
-      for (int i = 0; i < 12 + 5 * REVO_L; ++i) s_prof[i] = 0;
+        for (int i = 0; i < 12 + 5 * REVO_L; ++i) s_prof[i] = 0;
 #endif
+      }
     }
   }
   __syncthreads();
@@ -774,9 +808,8 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   int p = 0;
   for (;; ++p) {
     const int pb = p & 1, nb = pb ^ 1;
-    const PassCtl pc = s_pass[pb];
-    if (pc.mode == MODE_DONE) break;
-    const int l = pc.level;
+    const int mode = rfl_i(s_pass[pb].mode), l = rfl_i(s_pass[pb].level), ncand = rfl_i(s_pass[pb].ncand), phase = rfl_i(s_pass[pb].phase);
+    if (mode == MODE_DONE) break;
     Cam cam;
     cam.fx = prm.cam[l].fx; cam.fy = prm.cam[l].fy; cam.cx = prm.cam[l].cx; cam.cy = prm.cam[l].cy;
     cam.w = prm.cam[l].w; cam.h = prm.cam[l].h;
@@ -808,63 +841,58 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
         preg[k] = (i < N) ? pts[i] : f4v{0.f, 0.f, 1.f, 1.f};
       }
     }
-    const float ed = prm.edge_distance[l];
+    const float edist = prm.edge_distance[l];
     const bool filt = prm.use_edge_filter != 0;
-    float e[16];
+    // per thread: 27 normal-equation sums + the candidates' good counts (float, slots CSLOT..), and per candidate
+    // sum w r^2 / sum r^2 in double
+    float acc[32];
+    double ed[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) e[k] = 0.0f;
-    if (pc.mode == MODE_COST) {
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ed[k] = 0.0;
+    if (mode == MODE_COST) {
       // TrackerNew::evalCostFunction, tracker.cpp:357-393: nearest-pixel DT lookup, both poses in one pass
       float R[2][9], T[2][3];
       load_pose(s_cand[pb][0], R[0], T[0]);
       load_pose(s_cand[pb][1], R[1], T[1]);
-      float c0 = 0.0f, c1 = 0.0f;
 #pragma unroll
       for (int k = 0; k < TRACK_MAXP; ++k)
         if (first + k * stride < N) {
-          c0 += cost_point(preg[k], dtm, R[0], T[0], cam, ed, filt);
-          c1 += cost_point(preg[k], dtm, R[1], T[1], cam, ed, filt);
+          ed[0] += (double)cost_point(preg[k], dtm, R[0], T[0], cam, edist, filt);
+          ed[2] += (double)cost_point(preg[k], dtm, R[1], T[1], cam, edist, filt);
         }
       for (int i = first + TRACK_MAXP * stride; i < N; i += stride) {
         const f4v pt = pts[i];
-        c0 += cost_point(pt, dtm, R[0], T[0], cam, ed, filt);
-        c1 += cost_point(pt, dtm, R[1], T[1], cam, ed, filt);
+        ed[0] += (double)cost_point(pt, dtm, R[0], T[0], cam, edist, filt);
+        ed[2] += (double)cost_point(pt, dtm, R[1], T[1], cam, edist, filt);
       }
-      c0 += lane_xor<32>(c0); c1 += lane_xor<32>(c1);
-      c0 += lane_xor<16>(c0); c1 += lane_xor<16>(c1);
-      c0 += lane_xor<8>(c0); c1 += lane_xor<8>(c1);
-      c0 += lane_xor<4>(c0); c1 += lane_xor<4>(c1);
-      c0 += lane_xor<2>(c0); c1 += lane_xor<2>(c1);
-      c0 += lane_xor<1>(c0); c1 += lane_xor<1>(c1);
-      if (lane < NVAL) s_part[wave][lane] = (lane == ESLOT) ? c0 : (lane == ESLOT + 1 ? c1 : 0.0f);
     } else {
       const float huber = prm.huber_edge;
-      float acc[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-      if (pc.ncand == 4) fused_block<3>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, acc, e);
-      else if (pc.ncand == 3) fused_block<2>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, acc, e);
-      else if (pc.ncand == 2) fused_block<1>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, ed, filt, huber, acc, e);
+      if (ncand == 4) fused_block<3>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, edist, filt, huber, acc, ed);
+      else if (ncand == 3) fused_block<2>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, edist, filt, huber, acc, ed);
+      else if (ncand == 2) fused_block<1>(s_cand[pb], preg, pts, first, stride, N, dtm, cam, edist, filt, huber, acc, ed);
       else {  // a single candidate in full: residual + Jacobian + normal equations
         float R[9], T[3];
         load_pose(s_cand[pb][0], R, T);
 #pragma unroll
         for (int k = 0; k < TRACK_MAXP; ++k)
-          if (first + k * stride < N) full_point(preg[k], dtm, R, T, cam, ed, filt, huber, acc, e);
-        for (int i = first + TRACK_MAXP * stride; i < N; i += stride) full_point(pts[i], dtm, R, T, cam, ed, filt, huber, acc, e);
+          if (first + k * stride < N) full_point(preg[k], dtm, R, T, cam, edist, filt, huber, acc, ed);
+        for (int i = first + TRACK_MAXP * stride; i < N; i += stride) full_point(pts[i], dtm, R, T, cam, edist, filt, huber, acc, ed);
       }
-      PROF_MARK(te1);
-      PROF_MARK(te2);
-      reduce32(acc, lane);
-      reduce16(e, lane);
-      if (lane < 32) s_part[wave][idx32(lane)] = acc[0];
-      if (lane < 16) s_part[wave][ESLOT + idx16(lane)] = e[0];
-#ifdef REVO_TRACK_PROFILE
-      if (tid == 0) { s_prof[6] += te1 - tp0; s_prof[7] += te2 - te1; }
-#endif
+    }
+    PROF_MARK(te1);
+    {
+      int lane_r = lane;  // (opaque per pass, like the solver section's: the butterflies' `lane & MASK` predicates are nine SGPR pairs)
+      asm volatile("" : "+v"(lane_r));
+      reduce32(acc, lane_r);
+      reduce8d(ed, lane_r);
+      if (lane_r < 32) s_part[wave][idx32(lane_r)] = (double)acc[0];
+      if (lane_r < 8) s_part[wave][32 + idx8(lane_r)] = ed[0];
     }
 #ifdef REVO_TRACK_PROFILE
     const long long tp1 = clock64();
+    if (tid == 0) { s_prof[6] += te1 - tp0; s_prof[7] += tp1 - te1; }
 #endif
     __syncthreads();
 #ifdef REVO_TRACK_PROFILE
@@ -873,191 +901,238 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
 #endif
 
     if (wave < kmax) {  // ---- the solver waves: totals, the LM decision (redundantly), one candidate each
+      // The lane id, re-issued opaquely per pass: every `lane == i` / `row > k` predicate below is loop-invariant, IR-level LICM
+      // hoists them all in front of the pass loop, and ~40 exec-mask SGPR pairs kept alive across the evaluation come back as
+      // v_readlane pairs from spill registers on the serial path.  Derived from an opaque value they are one v_cmp where used.
+      int lane = lane_inv;
+      asm volatile("" : "+v"(lane));
+      // lane v < 32: total of float slot v; lanes 32 + 2k, 33 + 2k: total of double slot k (both lanes of the pair)
+      const int ri = lane < 32 ? lane : (lane < NVAL ? 32 + ((lane - 32) >> 1) : 0);
       double tot = 0.0;
       bool xok = true;
       if (redundant || wave == 0) {
-        if (lane < NVAL) {
 #pragma unroll
-          for (int wv = 0; wv < NWAVES; ++wv) tot += (double)s_part[wv][lane];
-        }
+        for (int wv = 0; wv < NWAVES; ++wv) tot += s_part[wv][ri];
       }
       if (!redundant) {
-        if (wave == 0) cluster_publish(mail_pair, cluster, member, epoch, (float)tot, lane);
+        if (wave == 0) cluster_publish(mail_pair, cluster, member, epoch, tot, lane);
         xok = cluster_gather(mail_pair, cluster, epoch, lane, &tot);
       }
-      const float tf = (float)tot;  // lane v: total of value v
+      const float tf = (float)tot;  // the reference's float accumulators, read once (optimizer.cpp:190, LGSX.h:320-326)
 #define TOT(v) rl(tf, (v))
+#define TOT_SW(j) rl(tf, 32 + 2 * DSLOT(j))   // sum w r^2 of candidate j
+#define TOT_N(j) rl(tf, CSLOT + (j))     // its good count
 #ifdef REVO_TRACK_PROFILE
       tp3 = clock64();
 #endif
-      const LMState S = s_st[pb];
-      LMState Nw = S;
-      PassCtl nx{MODE_EVAL, l, 1, PH_LM};
-      bool level_done = false, gen = false, single = false, take_ab = false;
-      float Rs[9], Ts[3];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Rs[i] = 0.0f;
-      Ts[0] = Ts[1] = Ts[2] = 0.0f;
-      float n_ab = 1.0f;  // point count of the evaluation the new normal equations come from
-      int consumed = 0;   // residual evaluations of the reference's sequence decided in this pass
+      SolverState& sv = s_sv[wave];
+      float lastErr = sv.lastErr, lambda = sv.lambda;
+      int iteration = rfl_i(sv.iteration), incTry = rfl_i(sv.incTry), total = rfl_i(sv.total_evals), flags = rfl_i(sv.flags);
+      int nmode = MODE_EVAL, nlevel = l, nncand = 1, nphase = PH_LM;
+      bool gen = false;
+      int consumed = 0;  // residual evaluations of the reference's sequence decided in this pass
+      float q[4], t[3];  // the accepted pose after this decision (Sophus::SE3f referenceToFrame)
 
-      if (!xok) {  // a cluster member never showed up: give up loudly instead of hanging
-        Nw.flags |= 8;
-        nx.mode = MODE_DONE;
-      } else if (pc.mode == MODE_COST) {  // tracker.cpp:272-282
-        const float costEye = TOT(ESLOT), costInit = TOT(ESLOT + 1);
+      if (!UNI(xok)) {  // a cluster member never showed up: give up loudly instead of hanging
+        flags |= 8;
+        nmode = MODE_DONE;
+      } else if (mode == MODE_COST) {  // tracker.cpp:272-282
+        const float costEye = TOT(32), costInit = TOT(36);  // double slots 0 and 2
+        float Rs[9], Ts[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rs[i] = d.R[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) Ts[i] = d.T[i];
-        if (costEye < costInit) {
+        if (UNI(costEye < costInit)) {
 #pragma unroll
           for (int i = 0; i < 9; ++i) Rs[i] = (i % 4 == 0) ? 1.0f : 0.0f;
           Ts[0] = Ts[1] = Ts[2] = 0.0f;
-          Nw.flags |= 1;
+          flags |= 1;
         }
-        quat_from_R(Rs, Nw.q);
-        Nw.t[0] = Ts[0]; Nw.t[1] = Ts[1]; Nw.t[2] = Ts[2];
-        nx.level = prm.lvl_begin; nx.phase = PH_FIRST;
-        single = true;
-        if (!is_orthogonal(Rs)) { Nw.flags |= 2; nx.mode = MODE_DONE; }  // Sophus::SE3f(R,T), optimizer.cpp:241
-      } else {
-        // error terms of candidate j: slots ESLOT + 3j .. +2 (sum w r^2, sum r^2, good count)
-        if (pc.phase == PH_EVAL_ONLY) {
-          const float n_f = TOT(ESLOT + 2);
-          const float an = __fdiv_rn(tf, n_f);  // LGS6 after finish(): A/n, b = -(sum w r v)/n, error = sum w r^2 / n
-          if (wave == 0 && member == 0) {
-            EvalOut& eo = eval_out[pair];
-            if (lane < 21) {
-              int r = 0, k = lane;
-              while (k >= 6 - r) { k -= 6 - r; ++r; }
-              eo.A[r * 6 + r + k] = an;
-              eo.A[(r + k) * 6 + r] = an;
-            } else if (lane < 27) {
-              eo.b[lane - 21] = -an;
-            } else if (lane == ESLOT) {
-              eo.error = an; eo.mean_err = an; eo.sum_w = tf;
-            } else if (lane == ESLOT + 1) {
-              eo.sum_u = tf;
-            } else if (lane == ESLOT + 2) {
-              eo.good = (int)tf; eo.bad = N - (int)tf;
-            }
+        quat_from_R(Rs, q);
+        nlevel = prm.lvl_begin; nphase = PH_FIRST;
+        if (!UNI(is_orthogonal(Rs))) { flags |= 2; nmode = MODE_DONE; }  // Sophus::SE3f(R,T), optimizer.cpp:241
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv.q[i] = q[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) sv.t[i] = Ts[i];
+          if (wave == 0) {
+            Cand& c = s_cand[nb][0];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) c.R[i] = Rs[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) c.T[i] = Ts[i];
           }
-          nx.mode = MODE_DONE;
-        } else if (pc.phase == PH_FIRST) {  // optimizer.cpp:243-250
-          const float n_f = TOT(ESLOT + 2);
-          const float err = __fdiv_rn(TOT(ESLOT), n_f);  // optimizer.cpp:190
-          Nw.good = (int)n_f; Nw.bad = N - (int)n_f; Nw.sumw = TOT(ESLOT); Nw.sumu = TOT(ESLOT + 1);
+        }
+      } else if (phase == PH_EVAL_ONLY) {
+        const float n_f = TOT_N(0);
+        const float an = __fdiv_rn(tf, n_f);  // LGS6 after finish(): A/n, b = -(sum w r v)/n, error = sum w r^2 / n
+        if (wave == 0 && member == 0) {
+          EvalOut& eo = eval_out[pair];
+          if (lane < 21) {
+            int r = 0, k = lane;
+            while (k >= 6 - r) { k -= 6 - r; ++r; }
+            eo.A[r * 6 + r + k] = an;
+            eo.A[(r + k) * 6 + r] = an;
+          } else if (lane < 27) {
+            eo.b[lane - 21] = -an;
+          } else if (lane == 32) {
+            eo.error = an; eo.mean_err = an; eo.sum_w = tf;
+          } else if (lane == 34) {
+            eo.sum_u = tf;
+          } else if (lane == CSLOT) {
+            eo.good = (int)tf; eo.bad = N - (int)tf;
+          }
+        }
+        nmode = MODE_DONE;
+      } else {
+        bool take_ab = false, level_done = false;
+        float n_ab = 1.0f;  // point count of the evaluation the new normal equations come from
+        int acc_j = -1;     // the accepted candidate of this pass
+        const int max_its = prm.max_its[l];
+        if (phase == PH_FIRST) {  // optimizer.cpp:243-250
+          const float n_f = TOT_N(0);
+          lastErr = __fdiv_rn(TOT_SW(0), n_f);  // optimizer.cpp:190
           consumed = 1;
-          Nw.lastErr = err; Nw.last_residual = err;
-          Nw.lambda = prm.lambda_initial[l];
-          Nw.iteration = 0; Nw.incTry = 0;
+          lambda = prm.lambda_initial[l];
+          iteration = 0; incTry = 0;
           take_ab = true; n_ab = n_f;
-          if (Nw.iteration < prm.max_its[l]) gen = true; else level_done = true;
-        } else if (pc.phase == PH_REFILL) {  // the normal equations at the pose an error-only candidate was accepted at
-          take_ab = true; n_ab = TOT(ESLOT + 2);
+          if (0 < max_its) gen = true; else level_done = true;
+        } else if (phase == PH_REFILL) {  // the normal equations at the pose an error-only candidate was accepted at
+          take_ab = true; n_ab = TOT_N(0);
           gen = true;
         } else {  // PH_LM: consume the candidates in the reference's order, optimizer.cpp:258-304
-          for (int j = 0; j < pc.ncand; ++j) {
-            const Cand& c = s_cand[pb][j];
-            const float sw = __shfl(tf, ESLOT + 3 * j), su = __shfl(tf, ESLOT + 3 * j + 1), n_f = __shfl(tf, ESLOT + 3 * j + 2);
-            const float err = __fdiv_rn(sw, n_f);
-            Nw.good = (int)n_f; Nw.bad = N - (int)n_f; Nw.sumw = sw; Nw.sumu = su;
-            consumed += 1;
-            if (err < Nw.lastErr) {  // accepted
+          int end_j = -1;  // the level ends at this (rejected) candidate: step too small, or the evaluation cap
+          bool capped = false;
+          float errA = 0.0f;
+          const float smin = prm.step_size_min[l];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) Nw.q[i] = c.q[i];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) Nw.t[i] = c.t[i];
-              if (__fdiv_rn(err, Nw.lastErr) > prm.convergence_eps[l]) Nw.iteration = prm.max_its[l];
-              Nw.lastErr = err; Nw.last_residual = err;
-              Nw.lambda = (c.lambda <= 0.2f) ? 0.0f : c.lambda * prm.lambda_success_fac;
-              Nw.iteration += 1;
-              Nw.incTry = 0;
-              if (Nw.iteration < prm.max_its[l]) {
-                if (j == 0) { take_ab = true; n_ab = n_f; gen = true; }
-                else {  // its Jacobian was not evaluated: one full pass at that pose
-                  single = true; nx.phase = PH_REFILL;
-#pragma unroll
-                  for (int i = 0; i < 9; ++i) Rs[i] = c.R[i];
-#pragma unroll
-                  for (int i = 0; i < 3; ++i) Ts[i] = c.T[i];
-                }
-              } else {
-                level_done = true;
-              }
-              break;
+          for (int j = 0; j < KMAX; ++j) {
+            if (j < ncand && acc_j < 0 && end_j < 0) {
+              const float err = __fdiv_rn(TOT_SW(j), TOT_N(j));
+              if (UNI(err < lastErr)) { acc_j = j; errA = err; }                   // accepted
+              else if (!UNI(s_cand[pb][j].incsq > smin)) end_j = j;                // rejected, and the step is too small to go on
+              else if (total + j + 1 > MAX_TOTAL_EVALS) { end_j = j; capped = true; }
             }
-            // rejected
-            if (!(c.incsq > prm.step_size_min[l])) { level_done = true; break; }
-            Nw.lambda = lambda_after_reject(c.lambda, prm.lambda_fail_fac, c.incTry);
-            Nw.incTry = c.incTry;
-            if (S.total_evals + consumed > MAX_TOTAL_EVALS) { level_done = true; Nw.flags |= 4; break; }
-            if (j == pc.ncand - 1) gen = true;  // every candidate of the pass was rejected: the chain goes on
+          }
+          consumed = acc_j >= 0 ? acc_j + 1 : (end_j >= 0 ? end_j + 1 : ncand);
+          if (acc_j >= 0) {
+            const float lamA = sv.lamc[acc_j];  // the damping this candidate was solved with
+            if (UNI(__fdiv_rn(errA, lastErr) > prm.convergence_eps[l])) iteration = max_its;
+            lastErr = errA;
+            lambda = (lamA <= 0.2f) ? 0.0f : lamA * prm.lambda_success_fac;
+            iteration += 1;
+            incTry = 0;
+            if (iteration < max_its) {
+              if (acc_j == 0) { take_ab = true; n_ab = TOT_N(0); gen = true; }
+              else {  // its Jacobian was not evaluated: one full pass at that pose
+                nphase = PH_REFILL;
+                if (wave == 0 && lane < 12) (&s_cand[nb][0].R[0])[lane] = (&s_cand[pb][acc_j].R[0])[lane];  // R[9], T[3]
+              }
+            } else {
+              level_done = true;
+            }
+          } else if (end_j >= 0) {
+            level_done = true;
+            if (capped) flags |= 4;
+          } else {  // every candidate of the pass was rejected: the chain goes on with the next dampings
+            const int tr_last = incTry + ncand;  // incTry of the last candidate (optimizer.cpp:263)
+            lambda = lambda_after_reject(sv.lamc[ncand - 1], prm.lambda_fail_fac, tr_last);
+            incTry = tr_last;
+            gen = true;
           }
         }
-        Nw.total_evals = S.total_evals + consumed;
+        total += consumed;
+        // the accepted pose: the accepted candidate's, otherwise unchanged
+        {
+          const float* qs = acc_j >= 0 ? s_cand[pb][acc_j].q : sv.q;
+          const float* ts = acc_j >= 0 ? s_cand[pb][acc_j].T : sv.t;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q[i] = qs[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) t[i] = ts[i];
+        }
         if (take_ab) abv = __fdiv_rn(tf, n_ab);  // LGS6::finish (LGSX.h:320-326): A/n and (sum w r v)/n, lane k = entry k
         if (level_done) {  // optimizer.cpp:308-309 -> next level or done (tracker.cpp:324-340)
-          quat_to_R(Nw.q, Rs);
-          Ts[0] = Nw.t[0]; Ts[1] = Nw.t[1]; Ts[2] = Nw.t[2];
-          single = true;
-          gen = false;
-          if (l > prm.lvl_end && !(Nw.flags & 4)) {
-            nx.level = l - 1; nx.phase = PH_FIRST;
-            float q2[4];
-            quat_from_R(Rs, q2);  // Sophus::SE3f(R,T) of the next level
+          float Rs[9];
+          quat_to_R(q, Rs);
+          if (wave == 0 && lane == 0) {
+            Cand& c = s_cand[nb][0];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Nw.q[i] = q2[i];
+            for (int i = 0; i < 9; ++i) c.R[i] = Rs[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) c.T[i] = t[i];
+          }
+          gen = false;
+          if (l > prm.lvl_end && !(flags & 4)) {
+            nlevel = l - 1; nphase = PH_FIRST;
+            quat_from_R(Rs, q);  // Sophus::SE3f(R,T) of the next level
           } else {
-            nx.mode = MODE_DONE;
+            nmode = MODE_DONE;
+          }
+        }
+        if (lane == 0) {
+          if (acc_j >= 0 || level_done) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv.q[i] = q[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sv.t[i] = t[i];
+          }
+          if (consumed) {  // ResidualInfo of the last evaluation the reference's sequence has seen
+            const int g = (int)rl(tf, CSLOT - 1 + consumed);
+            sv.good = g; sv.bad = N - g;
           }
         }
       }
       const int kspec = prm.kspec[l] < 1 ? 1 : (prm.kspec[l] > KMAX ? KMAX : prm.kspec[l]);  // gen stays on level l
       PROF_MARK(td1);
-      if (gen && nx.mode != MODE_DONE && wave < kspec) {  // candidate `wave` of the next pass: optimizer.cpp:258-269
-        float lam = Nw.lambda;
-        int tr = Nw.incTry;
-        for (int i = 0; i < wave; ++i) {  // as if candidates 0..wave-1 had been rejected
-          tr += 1;
-          lam = lambda_after_reject(lam, prm.lambda_fail_fac, tr);
-        }
-        tr += 1;
-        float inc[6], qn[4], tn[3], Rn[9];
-        solve6_ldlt(abv, lam, inc, lane);
-        PROF_MARK(td2);
-#ifdef REVO_TRACK_PROFILE
-        if (tid == 0) { s_prof[8] += td1 - tp3; s_prof[9] += td2 - td1; s_prof[10] += 1; }
-#endif
-        const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
-        se3_exp_mul(inc, Nw.q, Nw.t, qn, tn);
-        quat_to_R(qn, Rn);
+      if (gen) {  // the candidates of the next pass: optimizer.cpp:258-269 at the dampings the retries would see
+        float lamc[KMAX];
+        lamc[0] = lambda;
+#pragma unroll
+        for (int j = 1; j < KMAX; ++j) lamc[j] = lambda_after_reject(lamc[j - 1], prm.lambda_fail_fac, incTry + j);  // as if 0..j-1 had been rejected
         if (lane == 0) {
-          Cand& c = s_cand[nb][wave];
 #pragma unroll
-          for (int i = 0; i < 9; ++i) c.R[i] = Rn[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { c.T[i] = tn[i]; c.t[i] = tn[i]; }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) c.q[i] = qn[i];
-          c.incsq = incsq; c.lambda = lam; c.incTry = tr;
+          for (int j = 0; j < KMAX; ++j) sv.lamc[j] = lamc[j];
         }
+        if (wave < kspec) {
+          float lam = lamc[0];
+#pragma unroll
+          for (int j = 1; j < KMAX; ++j) lam = (wave == j) ? lamc[j] : lam;
+          float inc[6], qn[4], tn[3], Rn[9];
+          solve6_ldlt(abv, lam, inc, lane);
+          PROF_MARK(td2);
+#ifdef REVO_TRACK_PROFILE
+          if (tid == 0) { s_prof[8] += td1 - tp3; s_prof[9] += td2 - td1; s_prof[10] += 1; }
+#endif
+          const float incsq = inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2] + inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
+          se3_exp_mul(inc, q, t, qn, tn);
+          quat_to_R(qn, Rn);
+          if (lane == 0) {
+            Cand& c = s_cand[nb][wave];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) c.R[i] = Rn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) c.T[i] = tn[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c.q[i] = qn[i];
+            c.incsq = incsq;
+          }
+        }
+        nncand = kspec; nphase = PH_LM;
       }
-      if (gen && nx.mode != MODE_DONE) { nx.ncand = kspec; nx.phase = PH_LM; }
-      if (wave == 0 && lane == 0) {
-        if (single || nx.mode == MODE_DONE) {
-          Cand& c = s_cand[nb][0];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) c.R[i] = Rs[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) c.T[i] = Ts[i];
+      if (lane == 0) {
+        sv.lastErr = lastErr; sv.lambda = lambda;
+        sv.iteration = iteration; sv.incTry = incTry; sv.total_evals = total; sv.flags = flags;
+        if (wave == 0) {
+          s_pass[nb] = PassCtl{nmode, nlevel, nncand, nphase};
+          s_evals[l] += consumed;
         }
-        s_st[nb] = Nw;
-        s_pass[nb] = nx;
-        s_evals[l] += consumed;
       }
 #undef TOT
+#undef TOT_SW
+#undef TOT_N
     }
 #ifdef REVO_TRACK_PROFILE
     const long long tp5 = clock64();
@@ -1075,7 +1150,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
   }
 
   if (tid == 0 && member == 0 && !prm.eval_only) {
-    const LMState& s = s_st[p & 1];
+    const SolverState& s = s_sv[0];
     const Cand& c = s_cand[p & 1][0];
     revo_pair_result r;
 #pragma unroll
@@ -1088,7 +1163,7 @@ __global__ void __launch_bounds__(TRACK_THREADS) TRACK_OCC k_track(const PairDes
 #pragma unroll
       for (int i = 0; i < 3; ++i) r.T[i] = d.T[i];
     }
-    r.err = s.last_residual;
+    r.err = s.lastErr;  // last_residual (optimizer.cpp:276): always assigned together with lastErr
     r.good = s.good;
     r.bad = s.bad;
     // tracker.cpp:351-352

@@ -98,6 +98,48 @@ int main(int argc, char** argv) {
       if (std::memcmp(&hr[i], &ref[i], sizeof(revo_pair_result)) != 0) ++bad;
   }
   revo_pipeline_destroy(p);
+  // the result collective behind the C ABI: a world-size-1 RCCL communicator, windows of 2 steps gathered by the
+  // pipeline itself in the after-grid slot, 7 steps (3 complete windows + a flushed half one), ring of 2 window slots
+  {
+    char path[256]; int ver = 0;
+    OK(revo_comm_available(path, sizeof(path), &ver));
+    uint8_t id[REVO_COMM_ID_BYTES];
+    OK(revo_comm_unique_id(id));
+    revo_comm* comm = nullptr;
+    OK(revo_comm_create(ctx, id, 1, 0, &comm));
+    const int every = 2, ring = 2, csteps = 7;
+    revo_pair_result* d_gath = nullptr;
+    HIP(hipMalloc((void**)&d_gath, sizeof(revo_pair_result) * ring * 1 * every * n));
+    OK(revo_pipeline_create(ctx, n, 0, 0, &p));
+    OK(revo_pipeline_set_comm(p, comm, every, d_gath, ring));
+    std::vector<revo_pair_result> win((size_t)every * n);
+    int windows_checked = 0;
+    for (int t = 0; t < csteps; ++t) {
+      uint64_t ticket = 0;
+      OK(revo_pipeline_submit(p, d_bgr, d_dep, 0, 1.0, nullptr, nullptr, nullptr, &ticket, nullptr));
+      if ((t + 1) % every == 0) {  // the window's last step: its wait covers the collective
+        OK(revo_pipeline_wait(p, ticket, nullptr));
+        const int slot = (t / every) % ring;
+        HIP(hipMemcpy(win.data(), d_gath + (size_t)slot * every * n, sizeof(revo_pair_result) * every * n, hipMemcpyDeviceToHost));
+        for (int j = 0; j < every; ++j)
+          for (int i = 0; i < n; ++i)
+            if (std::memcmp(&win[(size_t)j * n + i], &ref[i], sizeof(revo_pair_result)) != 0) ++bad;
+        ++windows_checked;
+      }
+    }
+    int valid = -1, slot = -1;
+    OK(revo_pipeline_flush_comm(p, &valid, &slot));
+    OK(revo_pipeline_drain(p));
+    if (valid != csteps % every || slot != (csteps / every) % ring) ++bad;
+    HIP(hipMemcpy(win.data(), d_gath + (size_t)slot * every * n, sizeof(revo_pair_result) * every * n, hipMemcpyDeviceToHost));
+    for (int j = 0; j < valid; ++j)
+      for (int i = 0; i < n; ++i)
+        if (std::memcmp(&win[(size_t)j * n + i], &ref[i], sizeof(revo_pair_result)) != 0) ++bad;
+    std::printf("native collective: %s (nccl %d), %d windows + %d flushed step(s) gathered\n", path, ver, windows_checked, valid);
+    revo_pipeline_destroy(p);
+    revo_comm_destroy(comm);
+    (void)hipFree(d_gath);
+  }
   revo_ctx_destroy(ctx);
   (void)hipFree(d_bgr); (void)hipFree(d_dep); (void)hipFree(d_ref); (void)hipFree(d_out); (void)hipFree(d_copy);
   std::printf("pose0 T %.9g %.9g %.9g evals %d %d %d\n", ref[0].T[0], ref[0].T[1], ref[0].T[2], ref[0].evals[0], ref[0].evals[1], ref[0].evals[2]);

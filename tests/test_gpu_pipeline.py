@@ -183,3 +183,58 @@ def test_cpp_host_drives_the_pipeline_through_the_c_abi(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "PIPELINE_HOST_OK" in out.stdout, out.stdout + out.stderr
     assert "4 distinct hardware queues" in out.stdout, out.stdout
+    assert "native collective:" in out.stdout and "3 windows + 1 flushed step(s) gathered" in out.stdout, out.stdout
+
+
+def test_pipeline_gathers_its_records_through_the_native_rccl_communicator(api):
+    """SURVEY 8(e) behind the C ABI: revo_comm_* (RCCL loaded at run time, world size 1 here: the single-GPU CI of the 8-GPU
+    job) + revo_pipeline_set_comm -- the handle enqueues one all-gather per window of `every` steps in the after-grid slot of
+    the window's last step.  Every gathered record must be the bits the batch alone produces, for every = 1, 2, 3 and both
+    pipeline depths that alternate tracker streams (4) and do not (2); revo_pipeline_flush_comm covers an incomplete window; a
+    stand-alone revo_comm_allgather_records copies records bit for bit."""
+    import torch
+    from revo_amd._lib import RevoError
+    dev = torch.device("cuda", 0)
+    path, ver = api.rccl_available()
+    assert ver > 0, (path, ver)
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    api.TrackerNew(TrackerSettings(), s, cam)
+    n, nin = 6, 3
+    inputs = _inputs(s, n, nin, 2100, dev)
+    ref = _alone(api, cam, n, inputs, dev)
+    comm = api.Comm(cam, api.comm_unique_id(), 1, 0)
+    # the collective alone
+    send = torch.frombuffer(bytearray(ref[0]), dtype=torch.uint8).to(dev)
+    recv = torch.zeros_like(send)
+    comm.allgather_records(send.data_ptr(), recv.data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert recv.cpu().numpy().tobytes() == ref[0]
+    for depth, every in ((4, 2), (4, 1), (4, 3), (2, 2)):
+        ring = 3
+        pipe = api.Pipeline(cam, n, depth=depth)
+        with pytest.raises(RevoError):  # no host results, no communicator, no buffer: the records would be unreachable
+            pipe.submit(inputs[0][0].data_ptr(), inputs[0][1].data_ptr(), None)
+        gathered = torch.zeros(ring * 1 * every * n * 96, dtype=torch.uint8, device=dev)
+        pipe.set_comm(comm, every, gathered.data_ptr(), ring)
+        steps = 4 * every + (1 if every > 1 else 0)
+        own = torch.zeros(n * 96, dtype=torch.uint8, device=dev)
+        for t in range(steps):
+            bgr, dep = inputs[t % nin]
+            ticket, _ = pipe.submit(bgr.data_ptr(), dep.data_ptr(), own.data_ptr() if t == 0 else None)
+            if (t + 1) % every == 0:
+                pipe.wait(ticket)
+                k = t // every
+                w = gathered.view(ring, every * n * 96)[k % ring].cpu().numpy().tobytes()
+                for j in range(every):
+                    assert w[j * n * 96:(j + 1) * n * 96] == ref[(k * every + j) % nin], (depth, every, t, j)
+        valid, slot = pipe.flush_comm()
+        pipe.drain()
+        assert valid == steps % every and slot == (steps // every) % ring
+        w = gathered.view(ring, every * n * 96)[slot].cpu().numpy().tobytes()
+        for j in range(valid):
+            assert w[j * n * 96:(j + 1) * n * 96] == ref[((steps // every) * every + j) % nin]
+        assert own.cpu().numpy().tobytes() == ref[0]  # a caller buffer next to the communicator gets the step's own records
+        pipe.set_comm(None, 0, None, 0)  # detach
+        pipe.close()
+    comm.close()
