@@ -150,6 +150,27 @@ def run_tum_stream(a, device):
     out = {"folder": os.path.basename(os.path.normpath(a.tum_dir)), "frames": len(frames), "levels": 3,
            "frames_per_s": len(frames) / min(runs), "frames_per_s_runs": [len(frames) / t for t in runs],
            "keyframes": drv.nKeyFrames, "note": "decoded frames in host memory -> revo_vo_* (H2D + build on the IO thread)"}
+    # ... and from the PNG files: tum.DecodePool (decoder processes -> a page-locked ring the IO thread submits from in place),
+    # what `python -m revo_amd.run_tum` does; the single-process reader next to it (iowrapperRGBD.cpp:301-333 as the reference runs it)
+    rows = tum.read_associate(os.path.join(a.tum_dir, "associate.txt"), read_n_images=(a.tum_frames - 1) if a.tum_frames > 0 else None)
+    nd = tum.default_decoders()
+    dec_runs = []
+    for _ in range(2):
+        drv2 = vo.REVO(s3, cameraPyr=cam, depth_scale_factor=5000.0)
+        t0 = time.perf_counter()
+        with tum.DecodePool(a.tum_dir, rows, s3.width, s3.height, workers=nd) as pool:
+            pinned = pool.pinned
+            drv2.run(pool)
+        dec_runs.append(time.perf_counter() - t0)
+    same = len(drv2.poses) == len(drv.poses) and all(np.array_equal(p[1], q[1]) for p, q in zip(drv2.poses, drv.poses))
+    t0 = time.perf_counter()
+    n1 = min(len(rows), 60)
+    for r in rows[:n1]:
+        tum.load_frame(a.tum_dir, r[1], r[3])
+    one_decoder = n1 / (time.perf_counter() - t0)
+    out.update({"frames_per_s_incl_decode": len(rows) / min(dec_runs), "frames_per_s_incl_decode_runs": [len(rows) / t for t in dec_runs],
+                "decoder_processes": nd, "decode_ring_page_locked": bool(pinned), "poses_identical_to_predecoded_run": bool(same),
+                "one_decoder_frames_per_s": one_decoder})
     gt_file = os.path.join(a.tum_dir, "groundtruth.txt")
     if os.path.exists(gt_file):
         gt = tum.read_groundtruth_positions(gt_file)
@@ -326,6 +347,12 @@ def main():
                     help="lib (default): the timed loop drives the library's pipeline handle (revo_pipeline_*: it owns the four "
                          "streams, the batches and the event wiring); bench: the same choreography built here from the batch entry "
                          "points (round 4's loop, kept for A/B experiments with --track-streams / --edt-streams / --build-streams)")
+    ap.add_argument("--coll", default="torch", choices=["torch", "native"],
+                    help="who runs the path's only collective.  torch (default): torch.distributed's RCCL group, enqueued by this file in "
+                         "the pipeline's after-grid slot.  native: the library's own communicator (revo_comm_*, RCCL loaded by "
+                         "librevo_hip.so at run time) attached to the pipeline handle, which then enqueues the all-gather itself "
+                         "(revo_pipeline_set_comm: what a C++ host uses); torch.distributed only carries the control plane then "
+                         "(gloo: the 128-byte id, barriers, the max over ranks).  --shape lib only")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="steps per RCCL all_gather (the records of that many steps travel in one collective, in the after-grid slot "
                          "of the last of them); 0 = the default, 2 at every N (ranks then meet every second step only: a rank may lag "
@@ -459,17 +486,31 @@ def main():
     # The path's only collective runs through RCCL at every N, N = 1 included (the world-size-1
     # path is the single-GPU CI of the multi-GPU job).
     group_error = None
+    native = a.coll == "native"
+    if native and a.shape != "lib":
+        raise SystemExit("bench: --coll native needs --shape lib (the pipeline handle enqueues the collective)")
+    if native and a.no_collective:
+        raise SystemExit("bench: --coll native and --no-collective contradict each other")
     if world > 1 or not a.no_collective:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(parallel.free_port()))
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if native:  # control plane only: the data-path collective is the library's
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         except Exception as e:  # noqa: BLE001 -- N = 1 can still be measured without the group; N > 1 cannot
-            if world > 1:
+            if world > 1 or native:
                 raise
             group_error = "%s: %s" % (type(e).__name__, e)
     use_group = dist.is_initialized()
+    ctl_dev = "cpu" if native else dev  # where the control-plane tensors (times, rank ids) live
+    comm = None
+    if native:
+        uid = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = api.Comm(cam, uid[0], world, rank)  # ncclCommInitRank: every rank
 
     # The pipelined step: `nbuf` batches in rotation over four streams -- build(t+3) | edge lists + keyframe EDT(t+2) | the
     # tracker grids of steps t+1 and t on two alternating streams (the library's resident gate keeps two grids in flight).
@@ -505,7 +546,7 @@ def main():
         tracker's stream right behind the grid of the window's last step -- the after-grid slot of the pipeline (a fifth active
         stream would end up behind another stream's kernels in one of HIP's hardware queues: DESIGN 3.0).  Inside the timed
         region (synchronize + barrier below)."""
-        if not use_group:
+        if not use_group or native:  # (native: the pipeline handle enqueues the window's all-gather itself)
             return
         ev_grid[t % len(ev_grid)].record(s_tr)
         win = parallel.gather_window(t, every, start)
@@ -530,6 +571,12 @@ def main():
     if use_lib:
         pipe = api.Pipeline(cam, a.pairs, depth=nbuf)
         pipe_info = pipe.info()
+        NATIVE_RING = 4
+        d_gathered = None
+        if native:  # [ring][rank][step in window][pair] records, written by the handle's own all-gather
+            d_gathered = torch.zeros(NATIVE_RING * world * every * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev)
+            pipe.set_comm(comm, every, d_gathered.data_ptr(), NATIVE_RING)
+        native_last = [None]  # (slot, steps valid, first step) of the last window gathered
         counter = [0]
         phase_start = [0]
 
@@ -619,6 +666,14 @@ def main():
     def close_phase(end):
         """what the last window of a phase did not cover travels in one final collective"""
         tail = parallel.gather_tail(end, every, phase_start[0])
+        if native:  # an incomplete last window travels in one final collective of the handle's (every rank calls it)
+            valid, slot = pipe.flush_comm()
+            if valid:
+                native_last[0] = (slot, valid, end - valid)
+            elif end - phase_start[0] >= every:
+                nwin = pipe.info()["steps_submitted"] // every
+                native_last[0] = ((nwin - 1) % NATIVE_RING, every, end - every)
+            return
         if use_group and tail and (use_lib or a.coll_on_track):
             issue_gather(tail, s_tracks[(end - 1) % len(s_tracks)])
 
@@ -644,10 +699,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing[0] = False
-    ms_per_rank = [x / a.steps * 1e3 for x in parallel.gather_floats(mine_s, world, device=dev)] if use_group else [mine_s / a.steps * 1e3]
-    elapsed = parallel.max_over_ranks(elapsed, world, device=dev)
+    ms_per_rank = [x / a.steps * 1e3 for x in parallel.gather_floats(mine_s, world, device=ctl_dev)] if use_group else [mine_s / a.steps * 1e3]
+    elapsed = parallel.max_over_ranks(elapsed, world, device=ctl_dev)
     d_res = d_ress[(counter[0] - 1) % len(d_ress)]
-    if use_group:  # the gathered buffer of the last collective holds this rank's records of its window at its rank offset
+    if native:  # the window slot of the handle's last collective holds this rank's records of those steps at its rank offset
+        if native_last[0] is None:
+            raise SystemExit("bench: no native collective ran in the timed region")
+        slot, nst, first = native_last[0]
+        wb = every * a.pairs * parallel.RECORD_BYTES
+        mine = d_gathered[(slot * world + rank) * wb:(slot * world + rank) * wb + nst * a.pairs * parallel.RECORD_BYTES]
+        if not torch.equal(mine, d_res_all[first * a.pairs * 96:(first + nst) * a.pairs * 96]):
+            raise SystemExit("bench: the native RCCL gather did not return this rank's records")
+    elif use_group:  # the gathered buffer of the last collective holds this rank's records of its window at its rank offset
         got, win = gathered
         if got is None or got.numel() != world * win[1] * a.pairs * parallel.RECORD_BYTES:
             raise SystemExit("bench: gathered record buffer has the wrong size")
@@ -839,7 +902,7 @@ def main():
             del src, dst
         except RuntimeError:
             copy_gbs = None
-    seen, group_size = parallel.ranks_seen(world, device=dev) if use_group else ([0], 1)
+    seen, group_size = parallel.ranks_seen(world, device=ctl_dev) if use_group else ([0], 1)
     if use_group and (len(set(seen)) != world or group_size != world):
         raise SystemExit("bench: the process group saw ranks %s (size %d) but WORLD_SIZE is %d" % (seen, group_size, world))
     gather_us = None
@@ -849,10 +912,15 @@ def main():
         d_alone = torch.zeros(world * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev)
         e0.record()
         for _ in range(20):
-            parallel.gather_records(d_res, world, out=d_alone)
+            if native:
+                comm.allgather_records(d_res.data_ptr(), d_alone.data_ptr(), a.pairs, stream=torch.cuda.current_stream().cuda_stream)
+            else:
+                parallel.gather_records(d_res, world, out=d_alone)
         e1.record()
         torch.cuda.synchronize()
         gather_us = e0.elapsed_time(e1) * 1e3 / 20
+        if native and not torch.equal(d_alone[rank * a.pairs * 96:(rank + 1) * a.pairs * 96], d_res):
+            raise SystemExit("bench: revo_comm_allgather_records did not return this rank's records")
     out = {
         "metric": "tracked frames/sec at 640x480, 4-level pyramid; ATE vs reference",
         "value": world * a.pairs * a.steps / elapsed,
@@ -876,7 +944,7 @@ def main():
                         "(%s); per pair: 2 pyramid builds + keyframe (EDT+table) + trackFrames"
                         % (a.width, a.height, a.levels, a.pairs, baseline_config(a.width, a.height, a.levels, a.pairs, world)),
             "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
-            "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair x %d step(s) every %d step(s)" % (world, every, every),
+            "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair x %d step(s) every %d step(s)%s" % (world, every, every, " (native: revo_pipeline_set_comm)" if native else ""),
             "pipeline": ({"owner": "library (revo_pipeline_*)", **{k: v for k, v in pipe_info.items() if k != "streams"}} if use_lib
                          else {"owner": "bench.py (--shape bench: round 4's loop over the batch entry points)"}),
             "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
@@ -906,7 +974,10 @@ def main():
             # the kernel furthest below its roofline is the one to look at next
             "kernels": kernels,
         },
-        "collective": {"backend": "nccl (RCCL)" if use_group else None, "executed_every_step": bool(use_group) and every == 1,
+        "collective": {"backend": ("RCCL through the library's own communicator (revo_comm_* / revo_pipeline_set_comm; %s, nccl %d); control plane: gloo"
+                                   % api.rccl_available() if native else "nccl (RCCL)") if use_group else None,
+                       "enqueued_by": ("librevo_hip.so (pipeline handle, after-grid slot)" if native else "bench.py (torch.distributed, after-grid slot)") if use_group else None,
+                       "executed_every_step": bool(use_group) and every == 1,
                        "steps_per_collective": every if use_group else None, "inside_timed_region": bool(use_group),
                        "bytes_per_rank": a.pairs * parallel.RECORD_BYTES * every, "us_per_all_gather_alone": gather_us,
                        "ranks_seen": seen, "world_size": group_size,  # all_gather of the rank ids / dist.get_world_size()
@@ -928,6 +999,9 @@ def main():
     # the collective has done its job (and been timed): RCCL's proxy threads must not compete with the host-side
     # measurements below (IO thread + consumer thread of the sequential stream) for the cgroup's CPUs
     torch.cuda.synchronize()
+    if native:
+        pipe.set_comm(None, 0, None, 0)
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

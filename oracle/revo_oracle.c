@@ -23,6 +23,17 @@
 
 static int g_accum_double = 0;
 void ro_set_accum_double(int on) { g_accum_double = on; }
+/* Test hook (tests/test_oracle_tracker.py): every entry of the finished normal equations A/n, b/n moves by -1, 0 or +1 ulp
+ * (seeded, deterministic) -- what ANY other summation order, a fused multiply-add or a different compiler does to them.
+ * Shows how much of the accept / reject sequence of optimizer.cpp:258-304 is decided by the last bit of LGS6. */
+static unsigned g_ab_noise = 0;  /* 0 = off; otherwise the state of the generator */
+void ro_set_ab_ulp_noise(unsigned seed) { g_ab_noise = seed; }
+static float ab_noise(float v) {
+  g_ab_noise = g_ab_noise * 1664525u + 1013904223u;
+  const unsigned r = (g_ab_noise >> 16) % 3u;
+  if (r == 0 || !isfinite(v)) return v;
+  return nextafterf(v, r == 1 ? INFINITY : -INFINITY);
+}
 /* LM trace (test/analysis aid): one entry per residual evaluation after a level's first,
  * lvl*2 + accepted.  Not thread-safe: single-thread analysis only. */
 static int g_lm_trace_on = 0, g_lm_trace_n = 0;
@@ -950,6 +961,11 @@ static void calculate_warp_update(ro_tracker* t, ro_lgs6* ls, int good) {
   for (int a = 0; a < 36; ++a) ls->A[a] /= nc;
   for (int a = 0; a < 6; ++a) ls->b[a] /= nc;
   ls->error /= nc;
+  if (g_ab_noise) {  /* symmetric: the upper triangle's noise is mirrored */
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) { const float v = ab_noise(ls->A[c * 6 + r]); ls->A[c * 6 + r] = v; ls->A[r * 6 + c] = v; }
+    for (int a = 0; a < 6; ++a) ls->b[a] = ab_noise(ls->b[a]);
+  }
 }
 
 static int check_pair(const ro_pyramid* ref, const ro_pyramid* curr, int lvl) {

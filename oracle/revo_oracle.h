@@ -35,6 +35,8 @@ extern "C" {
 /* 0 = faithful (float, sequential order of the reference); 1 = accumulate the
  * long sums in double (used to quantify rounding, never as "the reference"). */
 void ro_set_accum_double(int on);
+/* test hook: +-1 ulp of seeded noise on every entry of the finished normal equations (0 = off) */
+void ro_set_ab_ulp_noise(unsigned seed);
 
 /* ---- image primitives --------------------------------------------------- */
 void ro_bgr2gray(const uint8_t* bgr, size_t stride, int w, int h, uint8_t* gray);

@@ -101,6 +101,7 @@ def lib():
         L.ro_edges3d.argtypes = [u8p, f32p, C.c_int, C.c_int] + [C.c_float] * 6 + [f32p]
         L.ro_u16_to_depth.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, C.c_int, C.c_int, C.c_double, f32p]
         L.ro_set_accum_double.argtypes = [C.c_int]
+        L.ro_set_ab_ulp_noise.argtypes = [C.c_uint]
         L.ro_vo_run_pipelined.restype = C.c_double
         L.ro_vo_run_pipelined.argtypes = [C.c_void_p, C.c_int, u8p, f32p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, f32p]
         L.ro_bench_pairs_pipelined.restype = None

@@ -169,23 +169,39 @@ def make_pair(seed, settings, max_t=0.03, max_rot_deg=1.5, hole_frac=0.03):
     return dict(ref=ref, curr=curr, T_ref_curr=T_ref_curr, T_w_ref=T_w_ref, T_w_curr=T_w_curr)
 
 
-def make_sequence(seed, settings, n_frames, max_t=0.012, max_rot_deg=0.6, hole_frac=0.03, bias=None):
+def _frame_job(args):
+    seed, T, k, i, hole_frac = args
+    return Scene(seed).render(T, *k, noise_seed=i, hole_frac=hole_frac)
+
+
+def make_sequence(seed, settings, n_frames, max_t=0.012, max_rot_deg=0.6, hole_frac=0.03, bias=None, workers=1):
     """Smooth random-walk trajectory (TUM-like stand-in): list of (bgr, depth, ts, T_w_c).
-    bias: optional constant twist added every frame (e.g. a steady pan that forces new keyframes)."""
+    bias: optional constant twist added every frame (e.g. a steady pan that forces new keyframes).
+    workers > 1: the frames are rendered on that many host cores (spawned like make_pairs; the same pixels: a frame depends on
+    the seed, its pose and its index only)."""
     rng = np.random.default_rng([seed, 23])
-    scene = Scene(seed)
     k = (settings.width, settings.height, settings.fx, settings.fy, settings.cx, settings.cy)
     T = np.eye(4)
     vel = random_twist(rng, max_t, max_rot_deg)
-    frames = []
+    poses = []
     for i in range(n_frames):
-        bgr, depth = scene.render(T, *k, noise_seed=i, hole_frac=hole_frac)
-        frames.append((bgr, depth, 1305031102.0 + i / 30.0, T.copy()))
+        poses.append(T.copy())
         vel = 0.85 * vel + 0.15 * random_twist(rng, max_t, max_rot_deg)
         # pull back towards the room centre so long sequences stay inside
         vel[:3] -= 0.02 * T[:3, :3].T @ T[:3, 3] * 0.05
         T = T @ se3_exp(vel if bias is None else vel + np.asarray(bias, np.float64))
-    return frames
+    jobs = [(seed, poses[i], k, i, hole_frac) for i in range(n_frames)]
+    import os
+    import sys
+    main = sys.modules.get("__main__")
+    if workers > 1 and os.path.isfile(getattr(main, "__file__", None) or ""):
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(workers, n_frames)) as pool:
+            imgs = pool.map(_frame_job, jobs, chunksize=max(1, n_frames // (4 * workers)))
+    else:
+        scene = Scene(seed)
+        imgs = [scene.render(poses[i], *k, noise_seed=i, hole_frac=hole_frac) for i in range(n_frames)]
+    return [(imgs[i][0], imgs[i][1], 1305031102.0 + i / 30.0, poses[i]) for i in range(n_frames)]
 
 
 def ate_rmse(est, gt):

@@ -118,3 +118,30 @@ def test_make_pairs_renders_the_same_pairs_on_several_cores():
         for k in ("ref", "curr"):
             assert np.array_equal(got[k][0], one[k][0]) and np.array_equal(got[k][1], one[k][1])
         assert np.array_equal(got["T_ref_curr"], one["T_ref_curr"])
+
+
+def test_decode_pool_delivers_the_same_frames_in_order(tmp_path):
+    """tum.DecodePool (several decoder processes -> a ring of frame slots in shared memory) yields exactly what the single-process
+    reader yields, in order, also when the ring is shorter than the sequence and the consumer is slow or fast; a broken file
+    surfaces as an error in the consumer."""
+    import time
+    import pytest
+    s = ImgPyramidSettings.scaled(160, 120, 3, hist_patch=(5, 0, 0, 0, 0, 0))
+    seq = synth.make_sequence(2, s, 9)
+    folder = str(tmp_path / "rgbd_dataset_synth")
+    tum.write_synthetic_dataset(folder, seq)
+    rows = tum.read_associate(folder + "/associate.txt")
+    want = list(tum.frames(folder))
+    for workers, ring, nap in ((3, 4, 0.0), (2, 3, 0.01), (1, 2, 0.0)):
+        with tum.DecodePool(folder, rows, 160, 120, workers=workers, ring=ring, pin=False) as pool:
+            got = []
+            for bgr, raw, ts in pool:
+                got.append((bgr.copy(), raw.copy(), ts))  # the views are only valid until the next frame is taken
+                time.sleep(nap)
+        assert len(got) == len(want)
+        for (b, d, t), (b0, d0, t0) in zip(got, want):
+            assert np.array_equal(b, b0) and np.array_equal(d, d0) and t == t0 and d.dtype == np.uint16
+    open(folder + "/" + rows[4][3], "wb").write(b"not a png")
+    with tum.DecodePool(folder, rows, 160, 120, workers=2, pin=False) as pool:
+        with pytest.raises(RuntimeError):
+            list(pool)

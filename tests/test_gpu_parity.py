@@ -568,11 +568,12 @@ def test_many_pairs_pose_parity_statistics(api, ro):
     print("pairs within 1e-5: %d/%d; max diff %.2e rad %.2e m; median GT error gpu %.2e oracle %.2e m"
           % (tight.sum(), n, drot.max(), dtr.max(), np.median(eg), np.median(eo)))
     assert tight.sum() >= int(0.9 * n)
-    # the stated tolerance, with an explicit allowance: at most 2 of the 48 pairs may sit inside the LM's 0.999
-    # convergence slack (a borderline accept/stop decision flips), and those by millimetres at most
+    # the stated tolerance, with an explicit allowance: at most 1 of the 48 pairs may sit inside the LM's 0.999
+    # convergence slack (a borderline accept/stop decision flips), and that one by less than 5e-4
+    # (round 6: was 2 pairs / 5e-3; measured: none outside, max 1.1e-5 rad / 2.3e-5 m)
     outside = ~((drot < ROT_TOL) & (dtr < TRANS_TOL))
-    assert outside.sum() <= 2, (np.nonzero(outside)[0].tolist(), drot[outside], dtr[outside])
-    assert drot.max() < 5e-3 and dtr.max() < 5e-3
+    assert outside.sum() <= 1, (np.nonzero(outside)[0].tolist(), drot[outside], dtr[outside])
+    assert drot.max() < 5e-4 and dtr.max() < 5e-4
     assert abs(np.median(eg) - np.median(eo)) < 1e-4
 
 

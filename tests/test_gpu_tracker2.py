@@ -288,8 +288,8 @@ def test_bench_configuration_every_pair_against_the_oracle(api, ro):
     inside = (drot < ROT_TOL) & (dtr < TRANS_TOL)
     print("bench config: %d/%d pairs within 1e-4; max %.2e rad %.2e m; identical evaluation counts: %d/%d"
           % (inside.sum(), n, drot.max(), dtr.max(), same_evals, n))
-    assert inside.sum() >= n - 2
-    assert drot.max() < 5e-3 and dtr.max() < 5e-3  # the slack of a borderline accept/stop decision, never more
+    assert inside.sum() >= n - 1
+    assert drot.max() < 5e-4 and dtr.max() < 5e-4  # the slack of a borderline accept/stop decision, never more (round 6: was n - 2 / 5e-3; measured 32 of 32, max 2.2e-5 rad / 4.2e-5 m)
 
 
 def test_shared_reciprocal_division_is_bit_identical_to_ieee(tmp_path):

@@ -4,7 +4,7 @@ checked by hand-run tools only.
 * the banded hysteresis (k_hyst_band / k_hyst_seam / k_hyst_out) forced at sizes where one workgroup per level would do,
   with three band sizes -- bit-exact vs the oracle on the Canny edge cases;
 * a 128-pair slice of tests/tools/soak_gpu_tracker.py at the bench geometry: the DISTRIBUTION behind the stated tracker
-  tolerance (>= 97 % of the pairs within 1e-5 rad / 1e-5 m of the faithful oracle, <= 2 % outside 1e-4, all within 5e-3;
+  tolerance (>= 97 % of the pairs within 1e-5 rad / 1e-5 m of the faithful oracle, <= 2 % outside 1e-4, all within 5e-4;
   DESIGN section 4) -- and the same pairs against the oracle with DOUBLE sums, whose accept / reject sequence the device follows.
 """
 import numpy as np
@@ -12,8 +12,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-# share of pairs on which the device takes exactly the accept / reject sequence of the oracle with double sums (measured: 99 of
-# 128 = 77 %, against 76 = 59 % for the float-sequential oracle; 127 of 128 poses within 1e-6: profiles/r05_parity_double_oracle.txt)
+# share of pairs on which the device takes exactly the accept / reject sequence of the oracle with double sums (measured: 98 of
+# 128 = 77 %, against 77 = 60 % for the float-sequential oracle; 127 of 128 poses within 1e-6: profiles/r06_parity_double_error_sums.txt)
 SAME_COUNTS_VS_DOUBLE_ORACLE = 0.70
 
 from revo_amd import synth  # noqa: E402
@@ -87,14 +87,17 @@ def test_tracker_tolerance_distribution_128_pairs(api, ro, capsys):
     (a) against the FAITHFUL oracle (float sums accumulated sequentially in the reference's list order, LGSX.h:392-398,
         optimizer.cpp:129-133).  Two faithful implementations of this LM may stop at different points inside its convergence
         slack (borderline `error < lastErr` / `> 0.999` decisions on sums of ~1e4 float terms, optimizer.cpp:273-278), so the
-        tolerance is a distribution: >= 97 % of the pairs within 1e-5 rad / 1e-5 m, <= 2 % outside 1e-4, none above 5e-3.
+        tolerance is a distribution: >= 97 % of the pairs within 1e-5 rad / 1e-5 m, <= 2 % outside 1e-4, none above 5e-4.
     (b) against the same oracle with its sums accumulated in DOUBLE (ro_set_accum_double: same algorithm, same order, the
         rounding noise of the sequential float sums removed).  The device sums per thread, folds by butterflies and finishes in
         double, i.e. it is close to the exact sums: if the float noise of the reference's own sums is what flips the borderline
         decisions, the device must follow THIS oracle's accept / reject sequence -- its per-level evaluation counts -- more
         often than (a)'s, its poses must agree to the last digits wherever the counts agree, and almost all poses must agree
         to 1e-6 (a flipped borderline decision late in a level usually ends at the same pose: measured 127 of 128 within 1e-6
-        while 99 of 128 count sequences are identical -- the device's sums are float per thread, not exact, so some flips remain).
+        while 98 of 128 count sequences are identical.  Round 6: the error sums the decisions compare are carried in double on the
+        device too, and the share stayed at 77 %: what flips the remaining decisions is the last bit of the 27 normal-equation
+        entries the candidate POSE is solved from -- the oracle against itself with +-1 ulp on A, b shows the same 77 %
+        (tests/test_oracle_tracker.py::test_one_ulp_on_the_normal_equations_changes_the_lm_sequence)).
     tests/test_oracle_tracker.py shows the CPU-only half of the argument: the oracle against ITSELF (float vs double sums)
     disagrees exactly like (a)."""
     import torch
@@ -151,11 +154,11 @@ def test_tracker_tolerance_distribution_128_pairs(api, ro, capsys):
     assert flagged == 0
     assert in5 >= 0.97 * n, "only %d of %d pairs within 1e-5" % (in5, n)
     assert out4 <= 0.02 * n, "%d of %d pairs outside 1e-4" % (out4, n)
-    assert drot.max() < 5e-3 and dtr.max() < 5e-3
+    assert drot.max() < 5e-4 and dtr.max() < 5e-4  # (round 6: was 5e-3; measured 8.0e-5 rad / 1.05e-4 m)
     # (b): the device follows the well-rounded reference
     assert same_d.mean() >= SAME_COUNTS_VS_DOUBLE_ORACLE, "identical evaluation counts vs the double-accumulating oracle: %d of %d" % (same_d.sum(), n)
     assert same_d.sum() > same_evals, "the device does not follow the double-accumulating oracle more often than the float one"
     assert worst_same[0] < 1e-6 and worst_same[1] < 1e-6, "same accept/reject sequence but different poses: %r" % (worst_same,)
-    assert in5_d >= 0.97 * n and out4_d <= 0.02 * n and drot_d.max() < 5e-3 and dtr_d.max() < 5e-3
+    assert in5_d >= 0.97 * n and out4_d <= 0.02 * n and drot_d.max() < 5e-4 and dtr_d.max() < 5e-4  # (measured 1.25e-4 rad / 3.2e-4 m)
     # ... and to SIX digits on all but the borderline pairs: the device IS the well-rounded reference (measured 127 of 128)
     assert in6_d >= 0.97 * n, "only %d of %d pairs within 1e-6 of the double-accumulating oracle" % (in6_d, n)

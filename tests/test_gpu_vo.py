@@ -64,6 +64,41 @@ def test_vo_matches_oracle_trajectory_and_keyframes():
     assert len(lines[0].split()[0].split(".")[1]) == 6 and all(len(ln.split()[0].split(".")[1]) == 9 for ln in lines[1:])
 
 
+def test_vo_at_the_metric_configuration_640x480_4_levels_120_frames():
+    """The configuration BASELINE's metric is quoted on, as a first-class sequential test:
+    640x480, 4-level pyramid, 120 frames of a TUM-like sweep through the product driver (IO thread + consumer loop,
+    system.cpp:96,128-284) and through the oracle's REVO::start -- the same keyframe decisions, ATE(gpu, oracle) < 1 mm,
+    per-frame poses within 5e-4, ATE against ground truth equal to 1 mm."""
+    from oracle import ro
+    from revo_amd import synth, vo
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(640, 480, 4, hist_patch=(20, 10, 5, 0, 0, 0))
+    n = 120
+    frames = synth.make_sequence(11, s, n, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(0.5), 0], workers=8)
+    gpu = vo.REVO(s)
+    res = gpu.run([(f[0], f[1], f[2]) for f in frames])  # the driver the bench's sequential stream uses
+    est_g = [r[0] for r in res]
+    kf_g = [i for i, r in enumerate(res) if r[1]]
+    cpu = ro.VO(s)
+    est_o, kf_o = [], []
+    for i, (bgr, depth, ts, T) in enumerate(frames):
+        po, ko = cpu.push(bgr, depth, ts)
+        est_o.append(po)
+        if ko:
+            kf_o.append(i)
+    gt = [f[3] for f in frames]
+    assert kf_g == kf_o and len(kf_g) >= 3, (kf_g, kf_o)
+    d_rot = max(synth.rot_angle(a[:3, :3], b[:3, :3]) for a, b in zip(est_g, est_o))
+    d_tr = max(float(np.linalg.norm(a[:3, 3] - b[:3, 3])) for a, b in zip(est_g, est_o))
+    ate_go = synth.ate_rmse(est_g, est_o)
+    ate_g, ate_o = synth.ate_rmse(est_g, gt), synth.ate_rmse(est_o, gt)
+    print("640x480x4, %d frames, keyframes at %s: max per-frame diff %.2e rad %.2e m; ATE(gpu,oracle) %.2e m; ATE vs GT gpu %.5f oracle %.5f m"
+          % (n, kf_g, d_rot, d_tr, ate_go, ate_g, ate_o))
+    assert ate_go < 1e-3
+    assert d_rot < 5e-4 and d_tr < 5e-4
+    assert abs(ate_g - ate_o) < 1e-3 and ate_g < 0.02
+
+
 def test_run_tum_cli_on_a_synthetic_tum_dataset(tmp_path, monkeypatch):
     """main.cpp's `REVO <settings.yaml> <dataset.yaml>` for a TUM-layout folder (PNG decode via PIL, u16
     depth converted on the device) vs the oracle's REVO::start on the same decoded frames."""
@@ -137,6 +172,40 @@ def test_bench_runs_a_tum_layout_folder(tmp_path):
     assert t["frames"] == 12 and t["frames_per_s"] > 0 and t["keyframes"] >= 1
     assert t["ate_rmse_vs_groundtruth_m"] < 5e-3
     assert t["trajectory_rmse_gpu_vs_oracle_m"] < 1e-3
+    # the same folder through the decoder pool (PNG files -> page-locked ring -> revo_vo_submit_u16): the same poses, bit for bit
+    assert t["poses_identical_to_predecoded_run"] and t["decoder_processes"] >= 1 and t["frames_per_s_incl_decode"] > 0
+
+
+def test_decoder_pool_keeps_the_sequential_stream_fed(tmp_path):
+    """SURVEY 8(f)-2 / iowrapperRGBD.cpp:301-333: "decode must not dominate".  A TUM-layout folder of 96 synthetic 640x480
+    frames, read by ONE decoder (the reference's arrangement) and by tum.DecodePool: the pool delivers the identical
+    trajectory, its ring is page-locked (the DMA engine reads the slots in place), and with the decoding spread over the host's
+    cores the stream runs well above what a single decoder can deliver."""
+    import time
+    from revo_amd import synth, tum, vo
+    from revo_amd.settings import ImgPyramidSettings
+    s3 = ImgPyramidSettings()
+    n = 96
+    seq = synth.make_sequence(5, s3, n, max_t=0.01, max_rot_deg=0.4, bias=[0.004, 0, 0, 0, np.deg2rad(0.5), 0], workers=8)
+    tum.write_synthetic_dataset(str(tmp_path), seq)
+    rows = tum.read_associate(str(tmp_path / "associate.txt"))
+    drv = vo.REVO(s3, depth_scale_factor=5000.0)
+    t0 = time.perf_counter()
+    want = drv.run(tum.frames(str(tmp_path)))
+    one = n / (time.perf_counter() - t0)
+    nd = tum.default_decoders()
+    rates = []
+    for _ in range(2):  # (the first run also pays for spawning the decoders)
+        drv2 = vo.REVO(s3, cameraPyr=drv.camPyr, depth_scale_factor=5000.0)
+        t0 = time.perf_counter()
+        with tum.DecodePool(str(tmp_path), rows, s3.width, s3.height, workers=nd) as pool:
+            assert pool.pinned
+            got = drv2.run(pool)
+        rates.append(n / (time.perf_counter() - t0))
+    assert len(got) == len(want) and all(np.array_equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(got, want))
+    print("sequential stream from PNG files: one decoder %.0f frames/s, %d decoder processes %.0f / %.0f frames/s" % (one, nd, rates[0], rates[1]))
+    if nd >= 4:
+        assert max(rates) > 2.0 * one, (one, rates)
 
 
 def test_page_locked_frames_are_read_in_place_and_give_the_same_bits(monkeypatch):

@@ -205,3 +205,40 @@ def test_reference_lm_is_only_defined_up_to_the_rounding_of_its_own_sums():
     assert same >= n // 4
     assert ((dr < 1e-4) & (dt < 1e-4)).sum() >= 0.9 * n and dr.max() < 5e-3 and dt.max() < 5e-3
     assert np.median(dr) < 1e-5 and np.median(dt) < 1e-5
+
+
+def test_one_ulp_on_the_normal_equations_changes_the_lm_sequence():
+    """Round 6: the device now carries the sums the decisions COMPARE (sum w r^2 per candidate, optimizer.cpp:129-133) in double
+    from the first addition on, and still takes exactly the double-accumulating oracle's accept / reject sequence on ~77 % of the
+    pairs only (tests/test_gpu_variants.py) -- the same share as before.  What decides the rest is upstream of the comparison:
+    the candidate POSE, i.e. the last bits of the 27 normal-equation entries the 6x6 solve starts from (LGSX.h:392-398).  Here
+    the oracle with exact (double) sums runs against ITSELF with every entry of the finished A/n, b/n moved by -1 / 0 / +1 ulp:
+    the perturbation any other summation order or instruction selection applies.  The evaluation counts then differ on a
+    sizeable share of the pairs while the poses stay together to ~1e-6: the reference's LM sequence is defined by the bits of
+    its own normal equations, its RESULT is not sensitive to them."""
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    trk = ro.Tracker(s, OptimizerSettings(), TrackerSettings())
+    L = ro.lib()
+    n, same, dr, dt = 40, 0, [], []
+    try:
+        L.ro_set_accum_double(1)
+        for seed in range(3000, 3000 + n):
+            pair = synth.make_pair(seed, s)
+            ref, cur = ro.Pyramid(s, *pair["ref"]), ro.Pyramid(s, *pair["curr"])
+            ref.makeKeyframe()
+            L.ro_set_ab_ulp_noise(0)
+            a = trk.trackFrames(ref, cur, np.eye(3), np.zeros(3))
+            L.ro_set_ab_ulp_noise(seed)
+            b = trk.trackFrames(ref, cur, np.eye(3), np.zeros(3))
+            same += list(a["evals"][:3]) == list(b["evals"][:3])
+            dr.append(synth.rot_angle(a["R"], b["R"]))
+            dt.append(float(np.linalg.norm(a["T"] - b["T"])))
+    finally:
+        L.ro_set_ab_ulp_noise(0)
+        L.ro_set_accum_double(0)
+    dr, dt = np.array(dr), np.array(dt)
+    print("oracle (double sums) vs itself with +-1 ulp on A, b: identical evaluation counts %d of %d, within 1e-6: %d, within 1e-5: %d, "
+          "max %.2e rad %.2e m" % (same, n, int(((dr < 1e-6) & (dt < 1e-6)).sum()), int(((dr < 1e-5) & (dt < 1e-5)).sum()), dr.max(), dt.max()))
+    assert same < n, "one ulp on the normal equations never changed a decision: the GPU's 77 % would need another cause"
+    assert same >= n // 4
+    assert ((dr < 1e-5) & (dt < 1e-5)).sum() >= 0.85 * n and dr.max() < 5e-3 and dt.max() < 5e-3
