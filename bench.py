@@ -160,8 +160,10 @@ def run_tum_stream(a, device):
         t0 = time.perf_counter()
         with tum.DecodePool(a.tum_dir, rows, s3.width, s3.height, workers=nd) as pool:
             pinned = pool.pinned
+            pool.warm()
+            t0 = time.perf_counter()  # (decoder start-up excluded: paid once per sequence)
             drv2.run(pool)
-        dec_runs.append(time.perf_counter() - t0)
+            dec_runs.append(time.perf_counter() - t0)
     same = len(drv2.poses) == len(drv.poses) and all(np.array_equal(p[1], q[1]) for p, q in zip(drv2.poses, drv.poses))
     t0 = time.perf_counter()
     n1 = min(len(rows), 60)
@@ -222,6 +224,12 @@ def dry_run_cpu(a, world, rank, json_fd):
     outs = {}
     pending = []  # (stream index, work handle, out tensor, first step, n steps)
     checked = [0]
+    # A LOGICAL clock next to the wall clock (the sleep-based check of "a late rank does not serialise the others"
+    # depends on the host's scheduling): a step costs --dry-run-step-ms of logical time (+ the delay on the late rank), every
+    # record carries the logical time at which its step ended, a collective completes at the maximum of the ranks' logical
+    # issue times, and waiting for it moves the waiting rank's clock there.  Deterministic: the schedule property is exact.
+    lt = [0.0]
+    min_issue_to_wait = [None]  # fewest steps between issuing a collective and first waiting for it (the after-grid slot: 2)
 
     def check(out, first, n):
         g = out.numpy().view(np.float32).reshape(world, n, a.pairs, nrec)
@@ -233,10 +241,15 @@ def dry_run_cpu(a, world, rank, json_fd):
                                      % (first, first + n - 1))
         checked[0] += n
 
-    def wait_stream(si):
+    def wait_stream(si, t_now=None):
         for item in [x for x in pending if x[0] == si or si < 0]:
             item[1].wait()
             check(item[2], item[3], item[4])
+            g = item[2].numpy().view(np.float32).reshape(world, item[4], a.pairs, nrec)
+            lt[0] = max(lt[0], float(g[:, item[4] - 1, 0, 11].max()))  # every rank had issued it by then (logical time)
+            if t_now is not None:
+                gap = t_now - (item[3] + item[4] - 1)
+                min_issue_to_wait[0] = gap if min_issue_to_wait[0] is None else min(min_issue_to_wait[0], gap)
             pending.remove(item)
 
     def issue(first, n, si):
@@ -246,14 +259,17 @@ def dry_run_cpu(a, world, rank, json_fd):
 
     def step(t, start):
         si = t % 2                       # the tracker stream of step t
-        wait_stream(si)                  # its grid sits behind whatever was enqueued on that stream before
+        wait_stream(si, t)               # its grid sits behind whatever was enqueued on that stream before
         if a.dry_run_step_ms > 0:
             time.sleep(a.dry_run_step_ms * 1e-3)
+            lt[0] += a.dry_run_step_ms
         if rank == a.dry_run_delay_rank and t == a.warmup + 2 and a.dry_run_delay_ms > 0:
             time.sleep(a.dry_run_delay_ms * 1e-3)
+            lt[0] += a.dry_run_delay_ms
         rec_all[t, :, 0] = seeds         # what a tracker would write: the pair's global index ...
         rec_all[t, :, 9] = rank          # ... the rank that "tracked" it ...
         rec_all[t, :, 10] = t            # ... and the step
+        rec_all[t, :, 11] = lt[0]        # ... and the logical time at which the step ended (the collective is issued then)
         win = parallel.gather_window(t, every, start)
         if win:
             issue(win[0], win[1], si)
@@ -262,20 +278,26 @@ def dry_run_cpu(a, world, rank, json_fd):
         for t in range(start, end):
             step(t, start)
         loop = time.perf_counter()
+        phase_lt[0] = lt[0]
         tail = parallel.gather_tail(end, every, start)  # what the last window did not cover travels in one final collective
         if tail:
             issue(tail[0], tail[1], (end - 1) % 2)
         wait_stream(-1)
         return loop
 
+    phase_lt = [0.0]
     phase(0, a.warmup)
     dist.barrier()
+    lt[0] = 0.0  # (float32 in the records: logical times stay small integers of milliseconds)
+    min_issue_to_wait[0] = None
     t0 = time.perf_counter()
     loop_s = phase(a.warmup, n_slots) - t0  # this rank's own loop: nobody has been waited for beyond the stream order
     mine_s = time.perf_counter() - t0
     dist.barrier()
     per_rank = parallel.gather_floats(mine_s, world)
     loop_per_rank = parallel.gather_floats(loop_s, world)
+    logical_per_rank = parallel.gather_floats(phase_lt[0], world)
+    gap_per_rank = parallel.gather_floats(float(min_issue_to_wait[0] if min_issue_to_wait[0] is not None else -1), world)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, world)
     seen, wsz = parallel.ranks_seen(world)
     if len(set(seen)) != world or wsz != world:
@@ -285,6 +307,8 @@ def dry_run_cpu(a, world, rank, json_fd):
                 "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
                 "ms_per_step_per_rank": [x / max(1, a.steps) * 1e3 for x in per_rank],
                 "ms_loop_per_rank": [x * 1e3 for x in loop_per_rank],
+                "logical_ms_loop_per_rank": logical_per_rank,  # the same loop on the logical clock: deterministic
+                "min_steps_between_issue_and_first_wait_per_rank": [int(x) for x in gap_per_rank],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none (stubbed step)",
                 "config": {"workload": "orchestration dry run on CPU (gloo): no kernels", "pairs_per_gpu": a.pairs,
                            "global_pairs": world * a.pairs},

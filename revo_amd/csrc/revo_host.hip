@@ -1702,7 +1702,12 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
   st.push_back({"k_edt_rows", 0, 2});
   const int n = (int)st.size();
   if (n > REVO_MAX_STAGES) return fail(REVO_ERR_CAPACITY, "too many stages");
-  std::vector<hipEvent_t> ev(n + 1);
+  struct Events {  // destroyed on every exit path (a HIPCHECK inside the loop used to leak them)
+    std::vector<hipEvent_t> v;
+    ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+  } evs;
+  evs.v.assign(n + 1, nullptr);
+  std::vector<hipEvent_t>& ev = evs.v;
   for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
   std::vector<double> sum(n, 0.0);
   for (int r = 0; r < reps; ++r) {
@@ -1726,7 +1731,6 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
       sum[i] += ms * 1e3;
     }
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   out->n = n;
   for (int i = 0; i < n; ++i) {
     out->us[i] = (float)(sum[i] / reps);

@@ -55,6 +55,9 @@ def _decode_worker(shm_name, width, height, folder, tasks, done):
             if t is None:
                 break
             i, slot, rf, df = t
+            if rf is None:  # warm(): "this decoder is up"
+                done.put((i, None))
+                continue
             try:
                 bgr, depth = load_frame(folder, rf, df)
                 if bgr.shape != (height, width, 3) or depth.shape != (height, width):
@@ -112,6 +115,15 @@ class DecodePool:
     @property
     def pinned(self):
         return self._pinned
+
+    def warm(self, timeout=60.0):
+        """Blocks until every decoder process has started (spawning a Python interpreter takes a few hundred milliseconds: a
+        caller that times a short sequence calls this first; a long run simply amortises it)."""
+        for k in range(self.workers):
+            self._tasks.put((-1 - k, 0, None, None))
+        for _ in range(self.workers):
+            self._done.get(timeout=timeout)
+        return self
 
     def _views(self, slot):
         nb = self.w * self.h * 3
