@@ -1036,13 +1036,27 @@ def main():
         from collections import deque
         hostb = {}
         for tag, scale in (("u16", 5000.0), ("f32", None)):
+            # the frames of a job lie back to back in TWO page-locked slabs, one per plane type ([2n][H][W][3] colours, [2n][H][W]
+            # depths): what a decoder that fills job-sized staging leaves behind -- the library then moves each slab in one
+            # copy (round 6; separately pinned frames, one copy each, reached 40 GB/s: REVO_BENCH_HOST_SLABS=0 restores them)
+            slabs = os.environ.get("REVO_BENCH_HOST_SLABS", "1") != "0"
+            nfr = 2 * len(rendered)
+            slab_c = torch.empty((nfr, a.height, a.width, 3), dtype=torch.uint8).pin_memory().numpy()
+            slab_d = torch.empty((nfr, a.height, a.width), dtype=torch.int16 if scale else torch.float32).pin_memory().numpy()
+            if scale:
+                slab_d = slab_d.view(np.uint16)
             fr = []
-            for r in rendered:
+            for i, r in enumerate(rendered):
                 one = []
-                for kb, kd in ((0, 1), (2, 3)):
+                for k, (kb, kd) in enumerate(((0, 1), (2, 3))):
                     d = np.clip(r[kd] * 5000.0, 0, 65535).astype(np.uint16) if scale else r[kd]
-                    one.append((torch.from_numpy(np.ascontiguousarray(r[kb])).pin_memory().numpy(),
-                                torch.from_numpy(np.ascontiguousarray(d)).pin_memory().numpy()))
+                    if slabs:
+                        slab_c[2 * i + k] = r[kb]
+                        slab_d[2 * i + k] = d
+                        one.append((slab_c[2 * i + k], slab_d[2 * i + k]))
+                    else:
+                        one.append((torch.from_numpy(np.ascontiguousarray(r[kb])).pin_memory().numpy(),
+                                    torch.from_numpy(np.ascontiguousarray(d)).pin_memory().numpy()))
                 fr.append(tuple(one))
             hb = api.HostBatchTracker(cam, depth_scale_factor=scale)
             ref_res = hb.track(fr)  # the records every later job must repeat
@@ -1073,6 +1087,7 @@ def main():
             hostb[tag] = {"value_incl_h2d": a.pairs * k_steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / k_steps * 1e3,
                           "h2d_bytes_per_step": step_bytes, "pcie_gbs": step_bytes * k_steps / dt_h / 1e9, "steps": k_steps,
                           "statistic": "median of the 3 repetitions after one untimed-in-the-statistic repetition of the same loop",
+                          "host_layout": "one page-locked slab per plane type and job (one copy each)" if slabs else "one page-locked buffer per frame and plane",
                           "value_incl_h2d_first_repetition": a.pairs * k_steps / first_rep,
                           "value_incl_h2d_runs": [a.pairs * k_steps / t for t in reps_h],
                           "pcie_gbs_runs": [step_bytes * k_steps / t / 1e9 for t in reps_h]}

@@ -1606,10 +1606,31 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
     }
   } slot_guard{c, j, cs, cs2};
   bool any_init = false;
-  auto upload = [&](void* dst, const void* src, size_t src_stride, size_t row_bytes, hipStream_t st) -> hipError_t {
-    if (src_stride == row_bytes) return hipMemcpyAsync(dst, src, row_bytes * h, hipMemcpyHostToDevice, st);  // (pieces were measured: slower)
-    return hipMemcpy2DAsync(dst, row_bytes, src, src_stride, row_bytes, h, hipMemcpyHostToDevice, st);
+  // Frames that lie back to back in host memory (a decoder that fills one job-sized slab per plane type: [2n][H][W][3] colours,
+  // [2n][H][W] depths) travel in ONE copy per run of adjacent frames instead of one per frame: the DMA engines reach the link's
+  // rate only with large transfers (profiles/r03_h2d_chunk_rates.txt: 0.6 MB pieces 43 GB/s on two streams, 1.2 MB 53 GB/s; a
+  // whole job's planes are 59 + 39 MB).  Frames that are not adjacent, or whose rows are padded, go one by one as before.
+  struct Run { char* dst; const char* src; size_t bytes; };
+  auto flush = [&](Run& r, hipStream_t st) -> hipError_t {
+    if (!r.bytes) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyHostToDevice, st);
+    r.bytes = 0;
+    return e;
   };
+  auto upload = [&](Run& r, void* dst, const void* src, size_t src_stride, size_t row_bytes, hipStream_t st) -> hipError_t {
+    if (src_stride != row_bytes) {  // padded rows: a strided copy of its own
+      const hipError_t e = flush(r, st);
+      if (e != hipSuccess) return e;
+      return hipMemcpy2DAsync(dst, row_bytes, src, src_stride, row_bytes, h, hipMemcpyHostToDevice, st);
+    }
+    const size_t bytes = row_bytes * h;
+    if (r.bytes && r.src + r.bytes == (const char*)src && r.dst + r.bytes == (char*)dst) { r.bytes += bytes; return hipSuccess; }
+    const hipError_t e = flush(r, st);
+    if (e != hipSuccess) return e;
+    r.dst = (char*)dst; r.src = (const char*)src; r.bytes = bytes;
+    return hipSuccess;
+  };
+  Run run_c{nullptr, nullptr, 0}, run_d{nullptr, nullptr, 0};
   for (int i = 0; i < n; ++i) {
     const revo_pair_in& p = pairs[i];
     const uint8_t* bs[2] = {p.ref_bgr, p.cur_bgr};
@@ -1618,13 +1639,15 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
     const size_t dst[2] = {p.ref_depth_stride, p.cur_depth_stride};
     for (int k = 0; k < 2; ++k) {
       const size_t f = 2 * (size_t)i + k;
-      HIPCHECK(upload(j->d_bgr + f * npix * 3, bs[k], bst[k], (size_t)w * 3, cs));
-      HIPCHECK(upload((char*)j->d_depth + f * npix * dsz, ds[k], dst[k], w * dsz, cs2));
+      HIPCHECK(upload(run_c, j->d_bgr + f * npix * 3, bs[k], bst[k], (size_t)w * 3, cs));
+      HIPCHECK(upload(run_d, (char*)j->d_depth + f * npix * dsz, ds[k], dst[k], w * dsz, cs2));
     }
     float* q = j->h_init + 12 * (size_t)i;
     if (p.use_init) { memcpy(q, p.R_init, sizeof(float) * 9); memcpy(q + 9, p.T_init, sizeof(float) * 3); any_init = true; }
     else { const float I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; memcpy(q, I, sizeof(I)); }
   }
+  HIPCHECK(flush(run_c, cs));
+  HIPCHECK(flush(run_d, cs2));
   HIPCHECK(hipEventRecord(j->ev_h2d2, cs2));
   HIPCHECK(hipStreamWaitEvent(cs, j->ev_h2d2, 0));
   HIPCHECK(hipEventRecord(j->ev_h2d, cs));

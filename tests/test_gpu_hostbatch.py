@@ -71,6 +71,24 @@ def test_host_buffer_batch_equals_device_pointer_batch(api):
             assert all(_same(a, b) for a, b in zip(hb.wait(j), want))
         errs = [synth.pose_error(r["R"], r["T"], p["T_ref_curr"]) for r, p in zip(got, pairs)]
         assert max(e[0] for e in errs) < 5e-3 and max(e[1] for e in errs) < 5e-3
+        # round 6: frames that lie back to back in two page-locked slabs (one per plane type) travel in one copy per slab;
+        # partly adjacent layouts (pair 2 elsewhere, pair 3's frames swapped in memory) split into several runs: same records
+        slab_c = torch.empty((2 * n + 2, s.height, s.width, 3), dtype=torch.uint8).pin_memory().numpy()
+        slab_d = torch.from_numpy(np.zeros((2 * n + 2, s.height, s.width), deps[0][0].dtype).view(np.int16 if u16 else np.float32)).pin_memory().numpy().view(deps[0][0].dtype)
+        for layout in ("adjacent", "broken"):
+            slot = list(range(2 * n))
+            if layout == "broken":
+                slot[4], slot[5] = 2 * n, 2 * n + 1      # pair 2 lives behind the others
+                slot[6], slot[7] = 7, 6                  # pair 3: current frame in front of the reference frame
+            slabbed = []
+            for i, p in enumerate(pairs):
+                fr = []
+                for k, name in enumerate(("ref", "curr")):
+                    slab_c[slot[2 * i + k]] = p[name][0]
+                    slab_d[slot[2 * i + k]] = deps[i][k]
+                    fr.append((slab_c[slot[2 * i + k]], slab_d[slot[2 * i + k]]))
+                slabbed.append(tuple(fr))
+            assert all(_same(a, b) for a, b in zip(hb.track(slabbed, init_RT=init), want)), (layout, u16)
 
 
 def test_host_buffer_batch_argument_errors(api):
