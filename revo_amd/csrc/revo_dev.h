@@ -39,6 +39,8 @@ struct PyrGeom {
   int total_nms_blocks, total_pix, total_edt_blocks, total_strips, total_cc;
   int total_bands, any_banded;  // hysteresis bands of all levels; 1 if some level has more than one
   int hyst_force;      // -1: banded hysteresis where a level does not fit one workgroup (default); 1 / 0: always / never (REVO_HYST_BANDED)
+  int hyst_heavy_runs; // MIXED hysteresis (levels that fit one workgroup): a level-0 frame with at least this many weak runs takes the
+                       // banded path, several workgroups, inside the same launch (REVO_HYST_HEAVY_RUNS; 0 = off: one workgroup per frame)
   int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
@@ -70,6 +72,7 @@ struct FramePlanes {
   int* strip_tot;              // [B][total_strips]: edge points per 64-column strip (the compaction's cross-strip offsets)
   uint32_t* ebits[REVO_L];     // banded hysteresis: the edge bitmap between its kernels (frame stride h*wpr)
   int* need_full;              // [B][REVO_L]: a band could not label its runs: k_hyst takes the whole (level, frame)
+  int* hyst_heavy;             // [B]: mixed hysteresis: 1 = level 0 of the frame went through the bands (its band records are valid)
   int* tile_base;              // [B][total_tiles]: first list position of every 32 x 32 tile (exclusive scan per level)
 };
 

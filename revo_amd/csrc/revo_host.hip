@@ -109,6 +109,7 @@ struct Knobs {
   int redundant_one;   // REVO_TRACK_REDUNDANT_ONE: levels up to this many points are evaluated redundantly by the single-pair launch
   int h2d_mode;        // REVO_H2D_STREAMS: 0 = colour and depth planes on two copy streams, 1 = one stream, 2 = swapped
   int direct_h2d;      // REVO_DIRECT_H2D (default 1): revo_pyramid_create reads page-locked caller rows in place (no staging copy)
+  int h2d_max_run_mb;  // REVO_H2D_MAX_RUN_MB: host-buffer batches merge adjacent frames into copies of at most this many MB
 };
 
 struct revo_ctx {
@@ -211,6 +212,9 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   }
   g->n_levels = L;
   { const char* e = getenv("REVO_HYST_BANDED"); g->hyst_force = (e && *e) ? (*e != '0' ? 1 : 0) : -1; }
+  // mixed hysteresis (round 6): where a level fits one workgroup, the frames whose level 0 has many weak runs (the launch used to
+  // last as long as the heaviest of them) are cut into bands inside the same launch; 0 = off
+  g->hyst_heavy_runs = env_int("REVO_HYST_HEAVY_RUNS", 4000, 0, 1 << 30);
   g->depth_min = s.depth_min; g->depth_max = s.depth_max;
   // cv::Canny with L2gradient: low/high swapped if needed, squared (imgpyramidrgbd.cpp:184)
   double lo = s.canny_threshold1, hi = s.canny_threshold2;
@@ -466,6 +470,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
     fs->p.strip_tot = (int*)take(sizeof(int) * (size_t)g.total_strips * B);
     fs->p.tile_base = (int*)take(sizeof(int) * (size_t)g.total_tiles * B);
     fs->p.need_full = (int*)take(sizeof(int) * REVO_L * B);
+    fs->p.hyst_heavy = (int*)take(sizeof(int) * B);
     if (with_staging) {
       fs->d_bgr = (uint8_t*)take((size_t)g.lv[0].npix * 3 * B);
       fs->d_depth = (float*)take((size_t)g.lv[0].npix * 4 * B);
@@ -547,6 +552,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   c->knobs.redundant_one = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
   c->knobs.h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
   c->knobs.direct_h2d = env_int("REVO_DIRECT_H2D", 1, 0, 1);
+  c->knobs.h2d_max_run_mb = env_int("REVO_H2D_MAX_RUN_MB", 64, 1, 4096);  // (profiles/r06_h2d_run_sizes.txt: 2 / 8 / 24 / 64 MB / unbounded)
   if (opt) c->os = *opt; else revo_opt_settings_default(&c->os);
   if (trk) c->ts = *trk; else revo_tracker_settings_default(&c->ts);
   std::string why;
@@ -1610,7 +1616,10 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
   // [2n][H][W] depths) travel in ONE copy per run of adjacent frames instead of one per frame: the DMA engines reach the link's
   // rate only with large transfers (profiles/r03_h2d_chunk_rates.txt: 0.6 MB pieces 43 GB/s on two streams, 1.2 MB 53 GB/s; a
   // whole job's planes are 59 + 39 MB).  Frames that are not adjacent, or whose rows are padded, go one by one as before.
+  // Runs are cut at 64 MB: measured (profiles/r06_h2d_run_sizes.txt) u16 depth 39 -> 49 GB/s, f32 43 -> 47 GB/s with the cut,
+  // but 39 GB/s when a job's 78 MB f32 depth slab travels as ONE copy (it then monopolises its engine past the colour copy).
   struct Run { char* dst; const char* src; size_t bytes; };
+  const size_t max_run = (size_t)c->knobs.h2d_max_run_mb << 20;  // REVO_H2D_MAX_RUN_MB: upper bound of one merged copy
   auto flush = [&](Run& r, hipStream_t st) -> hipError_t {
     if (!r.bytes) return hipSuccess;
     const hipError_t e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyHostToDevice, st);
@@ -1624,7 +1633,7 @@ extern "C" int revo_track_pairs_submit(revo_ctx* c, int n, const revo_pair_in* p
       return hipMemcpy2DAsync(dst, row_bytes, src, src_stride, row_bytes, h, hipMemcpyHostToDevice, st);
     }
     const size_t bytes = row_bytes * h;
-    if (r.bytes && r.src + r.bytes == (const char*)src && r.dst + r.bytes == (char*)dst) { r.bytes += bytes; return hipSuccess; }
+    if (r.bytes && r.bytes + bytes <= max_run && r.src + r.bytes == (const char*)src && r.dst + r.bytes == (char*)dst) { r.bytes += bytes; return hipSuccess; }
     const hipError_t e = flush(r, st);
     if (e != hipSuccess) return e;
     r.dst = (char*)dst; r.src = (const char*)src; r.bytes = bytes;

@@ -917,14 +917,10 @@ __device__ __forceinline__ BandRec band_rec(const FramePlanes& pl, const LevelGe
   return r;
 }
 
-__global__ void __launch_bounds__(HB_THREADS) k_hyst_band(PyrGeom g, FramePlanes pl) {
-  extern __shared__ uint32_t s_mem[];
+// A: one band of one (level, frame) -- the body of k_hyst_band, also called by the band workgroups of k_hyst_mixed
+__device__ __forceinline__ void hyst_band(const PyrGeom& g, const FramePlanes& pl, const BandRef br, const int f, uint32_t* s_mem) {
   __shared__ int s_wsum[HB_THREADS / 64];
   __shared__ int s_total;
-  // 1-D grid, band-major (level 0's bands first): consecutive ids = the same band of consecutive frames
-  const int nB = gridDim.x / g.total_bands;
-  const BandRef br = band_ref(g, blockIdx.x / nB);
-  const int f = g.frame0 + blockIdx.x % nB;
   const int l = br.l;
   const LevelGeom& lv = g.lv[l];
   const int h = lv.h, wpr = lv.wpr, pitch = wpr;
@@ -1105,6 +1101,62 @@ __global__ void __launch_bounds__(HB_THREADS) k_hyst_band(PyrGeom g, FramePlanes
   }
   for (int me = tid; me < nr; me += HB_THREADS) rec_out.root[me] = (unsigned short)(parent[me] & 0xffffu);
 }
+__global__ void __launch_bounds__(HB_THREADS) k_hyst_band(PyrGeom g, FramePlanes pl) {
+  extern __shared__ uint32_t s_mem[];
+  // 1-D grid, band-major (level 0's bands first): consecutive ids = the same band of consecutive frames
+  const int nB = gridDim.x / g.total_bands;
+  hyst_band(g, pl, band_ref(g, blockIdx.x / nB), g.frame0 + blockIdx.x % nB, s_mem);
+}
+
+// MIXED (round 6): the levels fit one workgroup, but the launch lasted as long as its heaviest level-0 frames -- a low-contrast
+// 640x480 frame has ~10 000 weak runs and its link phase alone is 80 k of 190 k cycles, bound by the LDS of the ONE CU it runs on
+// (random-access union-find: bank conflicts), while most frames take 45-75 k (profiles/r05_hyst_phase_profile.txt).  Here every
+// workgroup of frame f's level 0 first counts the frame's weak runs (the NMS bitmaps are in L2: 77 KB per frame); a frame with
+// at least g.hyst_heavy_runs of them is closed by its BAND workgroups (four CUs' LDS instead of one; their records in the
+// scratch plane, k_hyst_seam / k_hyst_out behind them, restricted to such frames), every other frame and every coarser level by
+// one workgroup as before -- all in ONE launch, the band workgroups first.  pl.hyst_heavy[f] tells the later kernels which
+// frames took the bands.  Both paths are bit-exact (the banded one is the default of big levels), so the mix is.
+__device__ __forceinline__ bool hyst_frame_is_heavy(const PyrGeom& g, const FramePlanes& pl, int f) {
+  __shared__ int s_cnt[HYST_THREADS / 64];
+  const LevelGeom& lv = g.lv[0];
+  const int nwords = lv.h * lv.wpr;
+  const uint2* cs = pl.cs[0] + (size_t)f * nwords;
+  int mine = 0;
+  for (int i = threadIdx.x; i < nwords; i += HYST_THREADS) {
+    const uint2 v = cs[i];
+    const uint32_t wk = v.x & ~v.y;
+    mine += __popc(wk & ~(wk << 1));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
+  __syncthreads();  // (s_cnt of an earlier item of this workgroup is no longer read)
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < HYST_THREADS / 64; ++k) total += s_cnt[k];
+  return total >= g.hyst_heavy_runs;
+}
+__global__ void __launch_bounds__(HYST_THREADS) k_hyst_mixed(PyrGeom g, FramePlanes pl, int n_frames) {
+  static_assert(HB_THREADS == HYST_THREADS, "one workgroup shape for both paths");
+  extern __shared__ uint32_t s_mem[];
+  const int nb0 = g.lv[0].nbands;
+  const int n_band_wg = nb0 * n_frames;
+  if ((int)blockIdx.x < n_band_wg) {  // band-major like k_hyst_band: consecutive ids = the same band of consecutive frames
+    const int f = g.frame0 + blockIdx.x % n_frames;
+    if (!hyst_frame_is_heavy(g, pl, f)) return;
+    hyst_band(g, pl, band_ref(g, blockIdx.x / n_frames), f, s_mem);
+    return;
+  }
+  const int item = blockIdx.x - n_band_wg;  // level-major, heaviest level first
+  const int l = item / n_frames, f = g.frame0 + item % n_frames;
+  if (l == 0) {
+    const bool heavy = hyst_frame_is_heavy(g, pl, f);
+    if (threadIdx.x == 0) pl.hyst_heavy[f] = heavy ? 1 : 0;
+    if (heavy) return;
+  }
+  hyst_level<true>(g, pl, l, f, s_mem);
+}
 
 // S: flags across the seams of one (level, frame).  One sweep over the seams lists the touching (run above, run below) pairs
 // as (band, root above, root below) in LDS -- the only part that reads HBM --, then the flags are OR-ed along the pairs
@@ -1112,17 +1164,19 @@ __global__ void __launch_bounds__(HB_THREADS) k_hyst_band(PyrGeom g, FramePlanes
 #define HS_THREADS 256
 #define HS_MAX_BANDS 32
 #define HS_MAX_PAIRS 6144
-__global__ void __launch_bounds__(HS_THREADS) k_hyst_seam(PyrGeom g, FramePlanes pl) {
+// mixed = 1 (k_hyst_mixed in front): the grid covers level 0 only, and only frames whose level 0 took the bands have records
+__global__ void __launch_bounds__(HS_THREADS) k_hyst_seam(PyrGeom g, FramePlanes pl, int mixed) {
   extern __shared__ uint32_t s_fl[];  // the bands' root flags, back to back (capb / 32 words per band)
   __shared__ uint2 s_pair[HS_MAX_PAIRS];
   __shared__ int s_npairs;
   __shared__ int s_changed_band[HS_MAX_BANDS];
-  const int nB = gridDim.x / g.n_levels;
+  const int nB = mixed ? gridDim.x : gridDim.x / g.n_levels;
   const int l = blockIdx.x / nB;
   const int f = g.frame0 + blockIdx.x % nB;
   const LevelGeom& lv = g.lv[l];
   const int nb = lv.nbands;
   if (nb <= 1 || pl.need_full[f * REVO_L + l]) return;
+  if (mixed && !pl.hyst_heavy[f]) return;
   const int wpr = lv.wpr, h = lv.h;
   const int tid = threadIdx.x;
   const int capb = band_capb(lv), fw = capb / 32;
@@ -1210,13 +1264,14 @@ __global__ void __launch_bounds__(HS_THREADS) k_hyst_seam(PyrGeom g, FramePlanes
 
 // P: promotions that came across a seam, then the band's outputs
 #define HO_THREADS 512
-__global__ void __launch_bounds__(HO_THREADS) k_hyst_out(PyrGeom g, FramePlanes pl) {
+__global__ void __launch_bounds__(HO_THREADS) k_hyst_out(PyrGeom g, FramePlanes pl, int mixed) {
   extern __shared__ uint32_t s_mem[];
-  const int nB = gridDim.x / g.total_bands;
+  const int nB = gridDim.x / (mixed ? g.lv[0].nbands : g.total_bands);  // mixed: the bands of level 0 only (they come first)
   const BandRef br = band_ref(g, blockIdx.x / nB);
   const int f = g.frame0 + blockIdx.x % nB;
   const int l = br.l;
   if (pl.need_full[f * REVO_L + l]) return;
+  if (mixed && !pl.hyst_heavy[f]) return;
   const LevelGeom& lv = g.lv[l];
   const int w = lv.w, h = lv.h, wpr = lv.wpr, pitch = wpr;
   const int hb = br.R1 - br.R0, nwb = hb * wpr;
@@ -2107,8 +2162,30 @@ void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
       if (lv.nbands > 1) seam_lds = std::max(seam_lds, (size_t)lv.nbands * (size_t)(HB_LDS_WORDS / 2 / 32 + 64) * 4);
     }
     hipLaunchKernelGGL(k_hyst_band, dim3(g.total_bands * B), dim3(HB_THREADS), HB_LDS_WORDS * 4, s, g, p);
-    if (g.any_banded) hipLaunchKernelGGL(k_hyst_seam, dim3(g.n_levels * B), dim3(HS_THREADS), seam_lds, s, g, p);
-    hipLaunchKernelGGL(k_hyst_out, dim3(g.total_bands * B), dim3(HO_THREADS), out_lds, s, g, p);
+    if (g.any_banded) hipLaunchKernelGGL(k_hyst_seam, dim3(g.n_levels * B), dim3(HS_THREADS), seam_lds, s, g, p, 0);
+    hipLaunchKernelGGL(k_hyst_out, dim3(g.total_bands * B), dim3(HO_THREADS), out_lds, s, g, p, 0);
+  }
+  // MIXED: every level fits one workgroup, level 0 has several bands, the knob is on: heavy level-0 frames through the bands,
+  // everything else through one workgroup, in one launch; then the seam and output passes of the heavy frames and the sweep for
+  // frames a band handed over (its runs exceeded its label space)
+  const bool mixed = !banded && fits_single && g.hyst_heavy_runs > 0 && g.total_bands > 0 && g.lv[0].nbands > 1;
+  if (mixed) {
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst_mixed), hipFuncAttributeMaxDynamicSharedMemorySize, REVO_HYST_LDS_MAX);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst_out), hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS_WORDS * 4);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyst_seam), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipGetLastError();
+      attr3 = true;
+    }
+    const LevelGeom& l0 = g.lv[0];
+    const size_t seam_lds = std::max<size_t>(4, (size_t)l0.nbands * (size_t)(HB_LDS_WORDS / 2 / 32 + 64) * 4);
+    const size_t out_lds = std::max<size_t>(4, (size_t)l0.band_rows * l0.wpr * 4);
+    hipLaunchKernelGGL(k_hyst_mixed, dim3((l0.nbands + g.n_levels) * B), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p, B);
+    hipLaunchKernelGGL(k_hyst_seam, dim3(B), dim3(HS_THREADS), seam_lds, s, g, p, 1);
+    hipLaunchKernelGGL(k_hyst_out, dim3(l0.nbands * B), dim3(HO_THREADS), out_lds, s, g, p, 1);
+    hipLaunchKernelGGL(k_hyst<true>, dim3(std::min(32, g.n_levels * B)), dim3(HYST_THREADS), REVO_HYST_LDS_MAX, s, g, p, 1, B);
+    return;
   }
   const int n_wg = only_flagged ? std::min(32, g.n_levels * B) : g.n_levels * B;
   if (ec_bytes + 4096 <= REVO_HYST_LDS_MAX)  // candidate bitmap + union-find labels in LDS: all of it (one workgroup per CU anyway)

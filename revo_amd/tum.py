@@ -188,14 +188,34 @@ class DecodePool:
             pass
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 hardware
+    threads and grant 16 CPUs: cpu.max = "1600000 100000")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def default_decoders():
-    """Decoder processes for a sequential run: the cores this process may use minus the two the driver's own threads (IO thread
-    + consumer loop, system.cpp:96) occupy, at most 16."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(16, n - 2))
+    """Decoder processes for a sequential run: HALF of the CPUs the process may really use (quota-aware), at most 12.  The other
+    half is for the driver's own threads (IO thread + consumer loop, system.cpp:96 -- the consumer polls) and for head-room:
+    measured on a 16-CPU-quota box (profiles/r06_decode_rates.txt), a pool of 8 decodes 690-820 frames/s, 12 about the same,
+    and 16 LESS (420-700: the quota throttles everything, the driver's threads included -- with the tracker running next to
+    16 decoders the stream fell to 215 frames/s)."""
+    return max(1, min(12, usable_cpus() // 2))
 
 
 def write_synthetic_dataset(folder, seq, depth_scale=5000.0):

@@ -80,6 +80,59 @@ def test_banded_and_single_hysteresis_agree_on_a_batch(api, monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("size,band_words", [((640, 480), 2400), ((320, 240), 600)])
+@pytest.mark.parametrize("heavy_runs", [1, 400])
+def test_mixed_hysteresis_bit_exact(api, ro, monkeypatch, size, band_words, heavy_runs):
+    """Round 6: levels that fit one workgroup take the MIXED hysteresis -- frames whose level 0 has at least
+    REVO_HYST_HEAVY_RUNS weak runs are closed by band workgroups inside the same launch, the others by one workgroup
+    (k_hyst_mixed + the seam / output passes of the heavy frames).  Threshold 1 sends every frame with a weak pixel through the
+    bands, 400 splits the edge cases between the two paths: bit-exact vs the oracle either way (imgpyramidrgbd.cpp:184)."""
+    w, h = size
+    monkeypatch.setenv("REVO_HYST_HEAVY_RUNS", str(heavy_runs))
+    monkeypatch.setenv("REVO_HYST_BAND_WORDS", str(band_words))
+    s = ImgPyramidSettings.scaled(w, h, 3, hist_patch=(20, 10, 5, 0, 0, 0) if w == 640 else (10, 5, 0, 0, 0, 0))
+    cam = api.CameraPyr(s)
+    for name, bgr, depth in _edge_cases(s):
+        gp = api.ImgPyramidRGBD(s, cam, bgr, depth)
+        op = ro.Pyramid(s, bgr, depth)
+        compare_pyramid("mixed%d_%dx%d_%s" % (heavy_runs, w, h, name), gp, op, s, False)
+
+
+def test_mixed_and_single_hysteresis_agree_on_the_bench_frames(api, monkeypatch):
+    """The first 8 bench pairs (16 frames of 640x480 x 4 levels, among them the low-contrast frames with ~10 000 weak runs that
+    made the single-workgroup launch as long as it was) through a batch with the mixed hysteresis as shipped, with every frame
+    forced through the bands, and with the mix switched off: identical edge planes, tile-ordered lists and tracker records."""
+    import torch
+    s = ImgPyramidSettings.scaled(640, 480, 4, hist_patch=(20, 10, 5, 0, 0, 0))
+    pairs = synth.make_pairs(range(8), s)
+    bgr = torch.from_numpy(np.stack([p[k][0] for p in pairs for k in ("ref", "curr")])).cuda()
+    dep = torch.from_numpy(np.stack([p[k][1] for p in pairs for k in ("ref", "curr")])).cuda()
+    recs = {}
+    for heavy in ("default", "1", "0"):
+        if heavy == "default":
+            monkeypatch.delenv("REVO_HYST_HEAVY_RUNS", raising=False)
+        else:
+            monkeypatch.setenv("REVO_HYST_HEAVY_RUNS", heavy)
+        cam = api.CameraPyr(s)
+        api.TrackerNew(TrackerSettings(), s, cam)
+        bt = api.BatchTracker(cam, 8)
+        res = torch.zeros(8 * 96, dtype=torch.uint8, device="cuda")
+        bt.track(bgr.data_ptr(), dep.data_ptr(), res.data_ptr())
+        bt.sync()
+        planes = []
+        for f in range(16):
+            v = bt.frame(f, s)
+            for lvl in range(4):
+                planes.append(v.returnEdges(lvl).copy())
+                planes.append(v.returnHist(lvl).copy() if s.hist_patch[lvl] > 0 else np.zeros(1))
+                planes.append(v.edges3DTiled(lvl).copy())
+        recs[heavy] = (res.cpu().numpy().tobytes(), planes)
+    for other in ("1", "0"):
+        assert recs["default"][0] == recs[other][0], "tracker records differ (REVO_HYST_HEAVY_RUNS=%s)" % other
+        for a, b in zip(recs["default"][1], recs[other][1]):
+            assert np.array_equal(a, b)
+
+
 def test_tracker_tolerance_distribution_128_pairs(api, ro, capsys):
     """The soak tool's statement as a test: 128 seeded 640x480 / 4-level pairs through bench-sized batches (32 pairs, the
     bench's cluster shape) against the oracle, pair by pair -- TWICE:
