@@ -347,36 +347,16 @@ def main():
     ap.add_argument("--tum-frames", type=int, default=200, help="frames of --tum-dir to run (0 = all)")
     ap.add_argument("--skip-host-buffers", action="store_true", help="skip the host-buffer (H2D-inclusive) side measurement")
     ap.add_argument("--no-collective", action="store_true", help="N = 1 only: do not create the world-size-1 RCCL group")
-    ap.add_argument("--track-streams", type=int, default=2,
-                    help="streams the tracker launches alternate over (the library keeps REVO_TRACK_DEPTH grids in flight, "
-                         "default 2; more streams than that buy nothing)")
-    ap.add_argument("--edt-streams", type=int, default=1,
-                    help="streams that run what the build leaves to its first consumer (revo_batch_prepare: the edge lists and the "
-                         "keyframes' distance transforms, REVO_DEFER); 0 = on the tracker's stream, in front of the grid (round 3)")
-    ap.add_argument("--track-priority", type=int, default=0, help="HIP stream priority of the tracker streams (-1 = high)")
-    ap.add_argument("--coll-own-stream", dest="coll_on_track", action="store_false",
-                    help="enqueue the step's RCCL all_gather on a stream of its own instead of on the tracker's stream, right behind "
-                         "the grid (default: HIP multiplexes its streams onto four hardware queues, and a fifth active stream ends up "
-                         "behind another one's kernels: profiles/r04_ab_pipeline_shapes.txt / r04_ab_queues_defer.txt)")
-    ap.set_defaults(coll_on_track=True)
-    ap.add_argument("--build-priority", type=int, default=0,
-                    help="HIP stream priority of the build stream(s) (-1 = high: the build chain is the critical one of the pipelined "
-                         "step and its kernels compete with the tracker streams' for free CUs)")
-    ap.add_argument("--build-streams", type=int, default=1, help="experiment: builds of consecutive steps alternate over this many streams")
     ap.add_argument("--input-batches", type=int, default=3,
                     help="distinct synthetic input batches rotated through the timed loop (3 x 138 MB at the default size: more "
                          "than the 256 MB Infinity Cache, so 'resident in HBM' cannot mean 'resident in the last-level cache')")
     ap.add_argument("--single-stream-runs", type=int, default=5, help="full-length runs of the sequential stream (median reported)")
-    ap.add_argument("--shape", default="lib", choices=["lib", "bench"],
-                    help="lib (default): the timed loop drives the library's pipeline handle (revo_pipeline_*: it owns the four "
-                         "streams, the batches and the event wiring); bench: the same choreography built here from the batch entry "
-                         "points (round 4's loop, kept for A/B experiments with --track-streams / --edt-streams / --build-streams)")
     ap.add_argument("--coll", default="torch", choices=["torch", "native"],
                     help="who runs the path's only collective.  torch (default): torch.distributed's RCCL group, enqueued by this file in "
                          "the pipeline's after-grid slot.  native: the library's own communicator (revo_comm_*, RCCL loaded by "
                          "librevo_hip.so at run time) attached to the pipeline handle, which then enqueues the all-gather itself "
                          "(revo_pipeline_set_comm: what a C++ host uses); torch.distributed only carries the control plane then "
-                         "(gloo: the 128-byte id, barriers, the max over ranks).  --shape lib only")
+                         "(gloo: the 128-byte id, barriers, the max over ranks)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="steps per RCCL all_gather (the records of that many steps travel in one collective, in the after-grid slot "
                          "of the last of them); 0 = the default, 2 at every N (ranks then meet every second step only: a rank may lag "
@@ -511,8 +491,6 @@ def main():
     # path is the single-GPU CI of the multi-GPU job).
     group_error = None
     native = a.coll == "native"
-    if native and a.shape != "lib":
-        raise SystemExit("bench: --coll native needs --shape lib (the pipeline handle enqueues the collective)")
     if native and a.no_collective:
         raise SystemExit("bench: --coll native and --no-collective contradict each other")
     if world > 1 or not a.no_collective:
@@ -537,10 +515,9 @@ def main():
         comm = api.Comm(cam, uid[0], world, rank)  # ncclCommInitRank: every rank
 
     # The pipelined step: `nbuf` batches in rotation over four streams -- build(t+3) | edge lists + keyframe EDT(t+2) | the
-    # tracker grids of steps t+1 and t on two alternating streams (the library's resident gate keeps two grids in flight).
-    # --shape lib (default): the library's pipeline handle owns all of it (revo_pipeline_*); --shape bench:
-    # the same choreography built here from the batch entry points (round 4's loop, for A/B experiments).
-    use_lib = a.shape == "lib"
+    # tracker grids of steps t+1 and t on two alternating streams (the library's resident gate keeps two grids in flight) --, all
+    # of it owned by the library's pipeline handle (revo_pipeline_*).  (Round 4's bench-owned loop over the batch entry points,
+    # `--shape bench`, was retired in round 6: its A/B role ended with profiles/r05_ab_lib_vs_bench.txt.)
     nbuf = 1 if a.no_overlap else max(2, a.buffers)
     d_bgrs = [torch.from_numpy(b).to(dev) for b in bgrs]
     d_deps = [torch.from_numpy(d).to(dev) for d in deps]
@@ -589,100 +566,27 @@ def main():
             gathered[0] = parallel.gather_records(src, world, out=d_alls[key])
         gathered[1] = win
 
-    pipe = None
-    track_events = []
     timing = [False]
-    if use_lib:
-        pipe = api.Pipeline(cam, a.pairs, depth=nbuf)
-        pipe_info = pipe.info()
-        NATIVE_RING = 4
-        d_gathered = None
-        if native:  # [ring][rank][step in window][pair] records, written by the handle's own all-gather
-            d_gathered = torch.zeros(NATIVE_RING * world * every * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev)
-            pipe.set_comm(comm, every, d_gathered.data_ptr(), NATIVE_RING)
-        native_last = [None]  # (slot, steps valid, first step) of the last window gathered
-        counter = [0]
-        phase_start = [0]
+    pipe = api.Pipeline(cam, a.pairs, depth=nbuf)
+    pipe_info = pipe.info()
+    NATIVE_RING = 4
+    d_gathered = None
+    if native:  # [ring][rank][step in window][pair] records, written by the handle's own all-gather
+        d_gathered = torch.zeros(NATIVE_RING * world * every * a.pairs * parallel.RECORD_BYTES, dtype=torch.uint8, device=dev)
+        pipe.set_comm(comm, every, d_gathered.data_ptr(), NATIVE_RING)
+    native_last = [None]  # (slot, steps valid, first step) of the last window gathered
+    counter = [0]
+    phase_start = [0]
 
-        def step():
-            t = counter[0]
-            counter[0] += 1
-            ticket, sh = pipe.submit(d_bgrs[t % nin].data_ptr(), d_deps[t % nin].data_ptr(), d_ress[t % len(d_ress)].data_ptr())
-            after_grid(t, ext(sh), phase_start[0])
-        s_track = ext(pipe_info["streams"][0])
-        s_tracks = [ext(h) for h in sorted(set(pipe_info["streams"][:2]), key=pipe_info["streams"].index)]
-        s_build = ext(pipe_info["streams"][2])
-        s_edts = [ext(pipe_info["streams"][3])] if pipe_info["streams"][3] != pipe_info["streams"][2] else []
-        bts = []
-    else:
-        pipe_info = None
-        nbuf_alloc = max(2, nbuf)
-        bts = [api.BatchTracker(cam, a.pairs) for _ in range(nbuf_alloc)]
-        s_track = torch.cuda.Stream(device=dev, priority=a.track_priority)
-        # the trackers of consecutive steps alternate between two streams: the library's resident gate (revo_host.hip) lets
-        # step k+1's tracker grid start filling the CUs that step k's finished pairs free, instead of idling behind k's slowest pair
-        n_tr = 1 if (a.no_overlap or os.environ.get("REVO_BENCH_ONE_TRACK_STREAM")) else max(1, min(a.track_streams, nbuf - 1))
-        s_tracks = [s_track] + [torch.cuda.Stream(device=dev, priority=a.track_priority) for _ in range(n_tr - 1)]
-        s_coll = torch.cuda.Stream(device=dev)    # carries the RCCL collective with --coll-own-stream
-        s_build = torch.cuda.Stream(device=dev, priority=a.build_priority)
-        # experiment knob: builds of consecutive steps on alternating streams (default: ONE build stream, the measured setup)
-        s_builds = [s_build] + [torch.cuda.Stream(device=dev, priority=a.build_priority) for _ in range(max(0, min(a.build_streams, nbuf - 1) - 1) if nbuf >= 2 else 0)]
-        s_edts = [torch.cuda.Stream(device=dev) for _ in range(max(0, a.edt_streams) if nbuf >= 2 else 0)]
-        phase_start = [0]
-
-        def make_step(nb, tracks, builds, edts, outs, main):
-            """One pipeline shape: `nb` batches in rotation, tracker grids alternating over `tracks`, builds over `builds`,
-            what a build leaves to its first consumer (edge lists + keyframe EDT, REVO_DEFER) on `edts` (empty: on the tracker's
-            stream).  main: the timed headline loop (records of every step kept, k_track timed live, the collective in the loop)."""
-            ev_built = [torch.cuda.Event() for _ in range(nb)]
-            ev_edt = [torch.cuda.Event() for _ in range(nb)]
-            ev_tracked = [torch.cuda.Event() for _ in range(nb)]
-            cnt = [0]
-
-            def step():
-                t = cnt[0]
-                k = t % nb
-                d_out = outs[t % len(outs)]
-                j_in = t % nin                      # the input batches rotate: step t reads input t mod nin
-                s_tr = tracks[t % len(tracks)]
-                cnt[0] += 1
-                if nb >= 2:
-                    s_bld = builds[t % len(builds)]
-                    s_bld.wait_event(ev_tracked[k])          # batch k free again (its previous tracker is done)
-                    bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_bld.cuda_stream, borrow_depth=True)
-                    ev_built[k].record(s_bld)
-                    if edts:  # the keyframes' EDT on its own stream: off the build stream's chain AND off the tracker's
-                        s_e = edts[t % len(edts)]
-                        s_e.wait_event(ev_built[k])
-                        bts[k].prepare(stream=s_e.cuda_stream)
-                        ev_edt[k].record(s_e)
-                        s_tr.wait_event(ev_edt[k])
-                    else:
-                        s_tr.wait_event(ev_built[k])
-                    if main and timing[0] and (cnt[0] % TIME_EVERY == 0):  # HIP events around the tracker launch, on its stream, inside the timed region
-                        e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        bts[k].prepare(stream=s_tr.cuda_stream)  # the keyframes' EDT the build left to this stream: not k_track
-                        e_a.record(s_tr)
-                        bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-                        e_b.record(s_tr)
-                        track_events.append((e_a, e_b))
-                    else:
-                        bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-                else:  # one batch, one stream: nothing overlaps anything
-                    bts[k].build(d_bgrs[j_in].data_ptr(), d_deps[j_in].data_ptr(), stream=s_tr.cuda_stream, borrow_depth=True)
-                    bts[k].track_only(d_out.data_ptr(), stream=s_tr.cuda_stream)
-                ev_tracked[k].record(s_tr)
-                if main:
-                    if a.coll_on_track:
-                        after_grid(t, s_tr, phase_start[0])
-                    elif use_group:  # --coll-own-stream: on a stream of its own behind the grid's event (every step)
-                        s_coll.wait_event(ev_tracked[k])
-                        with torch.cuda.stream(s_coll):
-                            gathered[0] = parallel.gather_records(d_out, world, out=d_alls.setdefault((1, 0), torch.zeros(world * a.pairs * 96, dtype=torch.uint8, device=dev)))
-                        gathered[1] = (t, 1)
-            return step, cnt
-
-        step, counter = make_step(nbuf, s_tracks, s_builds, s_edts, d_ress, True)
+    def step():
+        t = counter[0]
+        counter[0] += 1
+        ticket, sh = pipe.submit(d_bgrs[t % nin].data_ptr(), d_deps[t % nin].data_ptr(), d_ress[t % len(d_ress)].data_ptr())
+        after_grid(t, ext(sh), phase_start[0])
+    s_track = ext(pipe_info["streams"][0])
+    s_tracks = [ext(h) for h in sorted(set(pipe_info["streams"][:2]), key=pipe_info["streams"].index)]
+    s_build = ext(pipe_info["streams"][2])
+    s_edts = [ext(pipe_info["streams"][3])] if pipe_info["streams"][3] != pipe_info["streams"][2] else []
     torch.cuda.set_stream(s_track)
     stream = s_track.cuda_stream
     assert stream != 0 and s_build.cuda_stream != 0
@@ -698,7 +602,7 @@ def main():
                 nwin = pipe.info()["steps_submitted"] // every
                 native_last[0] = ((nwin - 1) % NATIVE_RING, every, end - every)
             return
-        if use_group and tail and (use_lib or a.coll_on_track):
+        if use_group and tail:
             issue_gather(tail, s_tracks[(end - 1) % len(s_tracks)])
 
     for _ in range(a.warmup):
@@ -710,8 +614,7 @@ def main():
     torch.cuda.synchronize()
     timing[0] = True
     phase_start[0] = a.warmup
-    if pipe is not None:
-        pipe.time_tracker(TIME_EVERY)
+    pipe.time_tracker(TIME_EVERY)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -742,17 +645,16 @@ def main():
         mine = got[rank * wb:(rank + 1) * wb]
         if not torch.equal(mine, d_res_all[win[0] * a.pairs * 96:(win[0] + win[1]) * a.pairs * 96]):
             raise SystemExit("bench: the RCCL gather did not return this rank's records")
-    if pipe is not None:
-        pipe.drain()
-        ms_live, n_live = pipe.tracker_ms()
-        pipe.time_tracker(0)
-        pipe_info = pipe.info()  # (steps_submitted = warm-up + timed steps)
+    pipe.drain()
+    ms_live, n_live = pipe.tracker_ms()
+    pipe.time_tracker(0)
+    pipe_info = pipe.info()  # (steps_submitted = warm-up + timed steps)
     gate = resident_gate_state(local_rank)
     if gate and gate["timeouts"]:
         print("bench: WARNING: %d resident gates gave up waiting (census %d of %d enqueued workgroups): tracker grids were "
               "held back for the gate's time-out -- the line below does not describe a healthy run" % (gate["timeouts"], gate["census"], gate["enqueued"]), file=sys.stderr)
     # one batch for the measurements outside the timed region (stage split, k_track alone, point counts)
-    bt = api.BatchTracker(cam, a.pairs) if use_lib else bts[(counter[0] - 1) % nbuf]
+    bt = api.BatchTracker(cam, a.pairs)
 
     # ---- correctness of what was timed (never skipped work): the flags of EVERY step, poses vs ground truth
     all_res = api.results_from_buffer(d_res_all.cpu().numpy().tobytes(), n_slots * a.pairs)
@@ -773,12 +675,10 @@ def main():
     # ---- roofline of the dominant kernel (k_track): HIP events on its stream around every launch of the
     # timed region (next to the other stream's build kernels); `kernel_ms_alone` re-times it with nothing else
     # running (revo_batch_time_tracker)
-    if use_lib:  # the pipeline handle's own event pairs (revo_pipeline_time_tracker), harvested after the drain
-        ms_track = float(ms_live) if n_live else None
-        n_timed = n_live
-    else:
-        ms_track = (float(np.mean([ea.elapsed_time(eb) for ea, eb in track_events])) if track_events else None)
-        n_timed = len(track_events)
+    # the pipeline handle's own event pairs (revo_pipeline_time_tracker: recorded inside the tracker chain, directly around the
+    # grid), harvested after the drain
+    ms_track = float(ms_live) if n_live else None
+    n_timed = n_live
     # algorithmic bytes per launch, SURVEY 8(d): B_trk = sum_l E_l*N_l*(16 + 4*16) + init check 2*N_c*(16+4) -- the mean
     # over the input batches of the rotation (every one is rebuilt and tracked once more here, outside the timed
     # region, to read its point counts; `kernel_ms_alone` averages over the same inputs)
@@ -827,15 +727,12 @@ def main():
     # (build -> keyframes -> tracker on one stream) and with TWO batches (the build of step k+1 next to the tracker of step
     # k, one tracker stream).  Same kernels, same inputs, no collective; 3 warm-up + 20 timed steps each, this rank only.
     def side_rate(nb):
-        if use_lib:
-            sp = api.Pipeline(cam, a.pairs, depth=nb)
-            cnt = [0]
+        sp = api.Pipeline(cam, a.pairs, depth=nb)
+        cnt = [0]
 
-            def st():
-                sp.submit(d_bgrs[cnt[0] % nin].data_ptr(), d_deps[cnt[0] % nin].data_ptr(), d_res_side.data_ptr())
-                cnt[0] += 1
-        else:
-            st, _ = make_step(nb, [s_track], [s_build], [], [d_res_side], False)
+        def st():
+            sp.submit(d_bgrs[cnt[0] % nin].data_ptr(), d_deps[cnt[0] % nin].data_ptr(), d_res_side.data_ptr())
+            cnt[0] += 1
         for _ in range(3):
             st()
         torch.cuda.synchronize()
@@ -844,8 +741,7 @@ def main():
             st()
         torch.cuda.synchronize()
         rate = a.pairs * 20 / (time.perf_counter() - t0s)
-        if use_lib:
-            sp.close()
+        sp.close()
         return rate
     value_single = side_rate(1) if not a.no_overlap else a.pairs * a.steps / elapsed
     value_two = side_rate(2) if not a.no_overlap else None
@@ -969,12 +865,11 @@ def main():
                         % (a.width, a.height, a.levels, a.pairs, baseline_config(a.width, a.height, a.levels, a.pairs, world)),
             "pairs_per_gpu": a.pairs, "global_pairs": world * a.pairs,
             "parallelism": "pairs sharded over %d GPU(s), one RCCL all_gather of 96 B/pair x %d step(s) every %d step(s)%s" % (world, every, every, " (native: revo_pipeline_set_comm)" if native else ""),
-            "pipeline": ({"owner": "library (revo_pipeline_*)", **{k: v for k, v in pipe_info.items() if k != "streams"}} if use_lib
-                         else {"owner": "bench.py (--shape bench: round 4's loop over the batch entry points)"}),
+            "pipeline": {"owner": "library (revo_pipeline_*)", **{k: v for k, v in pipe_info.items() if k != "streams"}},
             "pipelining": "none" if a.no_overlap else ("%d batches of %d pairs in rotation: the build of a later step overlaps the tracker grids of "
                                                         "earlier ones; consecutive tracker grids on %d stream(s), ordered by the library's "
                                                         "resident gate (at most %s in flight)%s" % (nbuf, a.pairs, len(s_tracks), os.environ.get("REVO_TRACK_DEPTH", "2"),
-                                                                                                  "; what the build leaves to its first consumer (REVO_DEFER=%s: 1 = the keyframes' EDT, 2 = + the edge lists, 3 = + hysteresis) on %d stream(s) of its own; the RCCL gather %s" % (os.environ.get("REVO_DEFER", "2"), len(s_edts), "on the tracker's stream, behind the grid" if (use_lib or a.coll_on_track) else "on its own stream") if s_edts else "")),
+                                                                                                  "; what the build leaves to its first consumer (REVO_DEFER=%s: 1 = the keyframes' EDT, 2 = + the edge lists, 3 = + hysteresis) on %d stream(s) of its own; the RCCL gather %s" % (os.environ.get("REVO_DEFER", "2"), len(s_edts), "on the tracker's stream, behind the grid") if s_edts else "")),
             "batches_in_rotation": nbuf, "pairs_resident": nbuf * a.pairs,
         },
         "roofline": {
@@ -987,7 +882,7 @@ def main():
             # complete; `frac` above is per launch as the rules ask, this is the same bytes over the step interval
             "frac_per_step_interval": b_trk / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
             "timing": "HIP events on the tracker's stream around %d of the %d launches of the timed region (every %d-th%s)"
-                      % (max(1, n_timed), a.steps, TIME_EVERY, "; recorded by the pipeline handle, revo_pipeline_time_tracker" if use_lib else ""),
+                      % (max(1, n_timed), a.steps, TIME_EVERY, "; recorded by the pipeline handle inside the tracker chain, directly around the grid: revo_pipeline_time_tracker"),
             "measured_copy_gbs": copy_gbs,  # on-box device-to-device copy ceiling (read + write bytes), for context
             # the WHOLE step against the roofline: SURVEY 8(d)'s bytes per independent frame-pair (2 B_pyr + B_kf + B_trk, with
             # this run's point counts and evaluation counts) x pairs / ms_per_step / peak -- per GPU

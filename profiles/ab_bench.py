@@ -11,7 +11,7 @@ one `profiles/build_var.sh` wrote to profiles/build/); an empty SPEC is the ship
 Every run is one `python bench.py --cpu-baseline off --single-stream-frames 0 --skip-host-buffers <args>` in a fresh process
 (the rendered inputs are cached under /tmp); the runs of the variants alternate so that box drift hits all of them alike.
 Prints one line per run and the mean per variant: frames/s, ms per step, build stage alone, tracker stage alone, k_track inside
-the pipelined step.  Bench arguments after a variant's `@`: NAME=SPEC@"--buffers 4 --track-streams 3".
+the pipelined step.  Bench arguments after a variant's `@`: NAME=SPEC@"--buffers 4 --gather-every 1".
 """
 import json
 import os

@@ -212,9 +212,10 @@ static int build_geom(const revo_pyr_settings& s, PyrGeom* g, std::string* why) 
   }
   g->n_levels = L;
   { const char* e = getenv("REVO_HYST_BANDED"); g->hyst_force = (e && *e) ? (*e != '0' ? 1 : 0) : -1; }
-  // mixed hysteresis (round 6): where a level fits one workgroup, the frames whose level 0 has many weak runs (the launch used to
-  // last as long as the heaviest of them) are cut into bands inside the same launch; 0 = off
-  g->hyst_heavy_runs = env_int("REVO_HYST_HEAVY_RUNS", 4000, 0, 1 << 30);
+  // mixed hysteresis (round 6): where a level fits one workgroup, the frames whose level 0 has at least this many weak runs (the
+  // launch lasts as long as the heaviest of them) are cut into bands inside the same launch.  Bit-exact and OFF by default (0):
+  // the band / seam / output passes of the heavy frames cost more than the single workgroup they replace
+  g->hyst_heavy_runs = env_int("REVO_HYST_HEAVY_RUNS", 0, 0, 1 << 30);  // measured and not kept as the default: profiles/r06_ab_mixed_hyst.txt
   g->depth_min = s.depth_min; g->depth_max = s.depth_max;
   // cv::Canny with L2gradient: low/high swapped if needed, squared (imgpyramidrgbd.cpp:184)
   double lo = s.canny_threshold1, hi = s.canny_threshold2;

@@ -283,7 +283,7 @@ def test_ab_bench_variant_specs():
     ab = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ab)
     assert ab.parse_variant("base=") == ("base", {}, [])
-    name, env, extra = ab.parse_variant("d3=REVO_TRACK_DEPTH=3,profiles/build/x.so@--buffers 4 --track-streams 3")
+    name, env, extra = ab.parse_variant("d3=REVO_TRACK_DEPTH=3,profiles/build/x.so@--buffers 4 --gather-every 1")
     assert name == "d3" and env["REVO_TRACK_DEPTH"] == "3" and env["REVO_HIP_SO"].endswith("profiles/build/x.so")
-    assert os.path.isabs(env["REVO_HIP_SO"]) and extra == ["--buffers", "4", "--track-streams", "3"]
+    assert os.path.isabs(env["REVO_HIP_SO"]) and extra == ["--buffers", "4", "--gather-every", "1"]
     assert ab.parse_variant("b2=@--build-streams 2") == ("b2", {}, ["--build-streams", "2"])
