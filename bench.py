@@ -782,6 +782,7 @@ def main():
               "k_canny_nms4": nframes * (SP + SP / 4),
               "hysteresis": nframes * (SP / 4 + SP + P_orig + SP / 8),
               "k_fill": None,
+              "k_edge_prefix": nframes * ((SP - P[-1]) / 8 + (SP - P[-1]) / 16),  # edge bitmaps in, one 16-bit prefix per 32-pixel word out
               "k_tile_count": nframes * (SP / 8 + SP / 8),
               "k_pts_tiles": nframes * (SP / 8 + SP / 8 + 4 * SN + 16 * SN),
               "k_edt_cols": a.pairs * (SP / 8 + 2 * SP),

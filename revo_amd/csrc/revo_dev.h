@@ -42,6 +42,8 @@ struct PyrGeom {
   int hyst_heavy_runs; // MIXED hysteresis (levels that fit one workgroup): a level-0 frame with at least this many weak runs takes the
                        // banded path, several workgroups, inside the same launch (REVO_HYST_HEAVY_RUNS; 0 = off: one workgroup per frame)
   int total_tiles;     // 32 x 32-pixel tiles of all levels (wpr x nchunk per level): the tracker's tile-ordered edge list
+  int pts_staged;      // per launch: 1 = the depths of the edge pixels of levels < n_levels - 1 were staged by the depth half of
+                       // k_pyrdown (k_edge_prefix in front of it): k_pts_tiles reads them from FramePlanes::stage, not from the depth planes
   float depth_min, depth_max;
   int canny_low, canny_high;  // squared L2 thresholds (cv::Canny, L2gradient=true)
   int use_edge_hist;
@@ -74,6 +76,11 @@ struct FramePlanes {
   int* need_full;              // [B][REVO_L]: a band could not label its runs: k_hyst takes the whole (level, frame)
   int* hyst_heavy;             // [B]: mixed hysteresis: 1 = level 0 of the frame went through the bands (its band records are valid)
   int* tile_base;              // [B][total_tiles]: first list position of every 32 x 32 tile (exclusive scan per level)
+  // staged edge depths (round 6; batches whose depth half of the pyramid runs behind Canny): the depth of every EDGE pixel of a
+  // level, compact, tiles in raster order and row-major inside a tile (the order of the tile-ordered list, valid depth or not)
+  float* stage[REVO_L];        // [B][npix] (capacity; ~10 % used)
+  unsigned short* epre[REVO_L];// [B][h * wpr]: edge pixels of the rows above (inside the 32-row tile) in word column wc
+  int* stage_base;             // [B][total_tiles]: first staging position of every tile (exclusive scan per level)
 };
 
 // One frame-pair for the tracker kernel.
@@ -130,7 +137,10 @@ struct EvalOut {
 void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_bgr, const float* d_depth_f32,
                        const uint16_t* d_depth_u16, float u16_alpha, int B, hipStream_t s);
 // parts: 3 = gray + depth in one launch, 1 = the gray half (Canny's input), 2 = the depth half (depth level + the source level's validity bits)
-void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s, int parts = 3);
+// stage_edges (parts = 2 only, launch_edge_prefix in front): the depth half also stages the depths of the source level's edge pixels
+void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s, int parts = 3, bool stage_edges = false);
+// per tile and row of levels < n_levels - 1: how many EDGE pixels lie in front (staging positions of launch_pyrdown(..., true))
+void launch_edge_prefix(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_hyst(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);
 void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s);

@@ -110,6 +110,7 @@ struct Knobs {
   int h2d_mode;        // REVO_H2D_STREAMS: 0 = colour and depth planes on two copy streams, 1 = one stream, 2 = swapped
   int direct_h2d;      // REVO_DIRECT_H2D (default 1): revo_pyramid_create reads page-locked caller rows in place (no staging copy)
   int h2d_max_run_mb;  // REVO_H2D_MAX_RUN_MB: host-buffer batches merge adjacent frames into copies of at most this many MB
+  int stage_edge_depths;  // REVO_STAGE_EDGE_DEPTHS (default 1): pipelined batches stage the edge pixels' depths in the depth pass
 };
 
 struct revo_ctx {
@@ -464,6 +465,10 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
       fs->p.cmask[l] = (unsigned*)take((size_t)v.w * v.nchunk * B * 4);
       fs->p.vb[l] = (uint8_t*)take((n + 7) / 8);
       fs->p.ebits[l] = (uint32_t*)take((size_t)v.h * v.wpr * 4 * B);
+      if (B > 1 && l < g.n_levels - 1) {  // (batches only: the single-frame API builds its depth pyramid in front of Canny)
+        fs->p.stage[l] = (float*)take(n * 4);
+        fs->p.epre[l] = (unsigned short*)take((size_t)v.h * v.wpr * 2 * B);
+      }
     }
     fs->own_depth0 = fs->p.depth[0];
     fs->p.npts = (int*)take(sizeof(int) * REVO_L * B);
@@ -472,6 +477,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
     fs->p.tile_base = (int*)take(sizeof(int) * (size_t)g.total_tiles * B);
     fs->p.need_full = (int*)take(sizeof(int) * REVO_L * B);
     fs->p.hyst_heavy = (int*)take(sizeof(int) * B);
+    fs->p.stage_base = (int*)take(sizeof(int) * (size_t)g.total_tiles * B);
     if (with_staging) {
       fs->d_bgr = (uint8_t*)take((size_t)g.lv[0].npix * 3 * B);
       fs->d_depth = (float*)take((size_t)g.lv[0].npix * 4 * B);
@@ -553,6 +559,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   c->knobs.redundant_one = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
   c->knobs.h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
   c->knobs.direct_h2d = env_int("REVO_DIRECT_H2D", 1, 0, 1);
+  c->knobs.stage_edge_depths = env_int("REVO_STAGE_EDGE_DEPTHS", 1, 0, 1);
   c->knobs.h2d_max_run_mb = env_int("REVO_H2D_MAX_RUN_MB", 64, 1, 4096);  // (profiles/r06_h2d_run_sizes.txt: 2 / 8 / 24 / 64 MB / unbounded)
   if (opt) c->os = *opt; else revo_opt_settings_default(&c->os);
   if (trk) c->ts = *trk; else revo_tracker_settings_default(&c->ts);
@@ -678,11 +685,19 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
     // ... with the depth half of the pyramid in front of them when the build left it out (nothing on the build stream reads the
     // coarser depth levels or the validity bits: they feed the edge lists only).  Only then: with REVO_SPLIT_DEPTH=0 the build ran
     // the fused kernel and the depth half must not run a second time.
+    PyrGeom gp = c->geom;
     if (fs->depth_pending) {
-      for (int l = 1; l < c->geom.n_levels; ++l) launch_pyrdown(c->geom, fs->p, l, fs->B, s, 2);
+      // ... and the edges are final by now, so the depth pass -- which streams every depth of a level anyway -- also leaves the
+      // depths of the level's EDGE pixels behind, compact and in list order (k_edge_prefix tells it where): the edge-list
+      // write then reads ~10 MB of staged depths instead of every 128-byte line of the depth planes that holds an edge
+      // pixel (~100 MB per 64-frame batch).  REVO_STAGE_EDGE_DEPTHS=0: gather from the planes as before.
+      const bool stage = c->knobs.stage_edge_depths && fs->p.stage[0] != nullptr && c->geom.n_levels > 1;
+      if (stage) launch_edge_prefix(c->geom, fs->p, fs->B, s);
+      for (int l = 1; l < c->geom.n_levels; ++l) launch_pyrdown(c->geom, fs->p, l, fs->B, s, 2, stage);
+      gp.pts_staged = stage ? 1 : 0;
       fs->depth_pending = false;
     }
-    launch_tile_points(c->geom, fs->p, fs->B, s);
+    launch_tile_points(gp, fs->p, fs->B, s);
     fs->pts_pending = false;
   }
   launch_keyframe(c->geom, fs->p, 0, 2, fs->edt_count, s);
@@ -1728,6 +1743,11 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
   st.push_back({"k_canny_nms4", 0, 0});
   st.push_back({"hysteresis", 0, 0});
   st.push_back({"k_fill", 0, 0});
+  // (as a pipelined batch runs it: the depth half stages the edge pixels' depths when the knob is on)
+  const bool stage = c->knobs.stage_edge_depths && fs->p.stage[0] != nullptr && L > 1;
+  PyrGeom gp = g;
+  gp.pts_staged = stage ? 1 : 0;
+  if (stage) st.push_back({"k_edge_prefix", 0, 0});
   for (int l = 1; l < L; ++l) st.push_back({"k_pyrdown_depth", l, 2});
   st.push_back({"k_tile_count", 0, 1});
   st.push_back({"k_pts_tiles", 0, 2});
@@ -1748,11 +1768,13 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
     for (int i = 0; i < n; ++i) {
       const std::string nm = st[i].name;
       if (nm == "k_gray_depth") launch_gray_depth(g, fs->p, d_bgr, d_depth, nullptr, 0.f, B, s);
-      else if (nm == "k_pyrdown_gray" || nm == "k_pyrdown_depth") launch_pyrdown(g, fs->p, st[i].a, B, s, st[i].w);
+      else if (nm == "k_pyrdown_gray") launch_pyrdown(g, fs->p, st[i].a, B, s, 1);
+      else if (nm == "k_pyrdown_depth") launch_pyrdown(g, fs->p, st[i].a, B, s, 2, stage);
+      else if (nm == "k_edge_prefix") launch_edge_prefix(g, fs->p, B, s);
       else if (nm == "k_canny_nms4") launch_canny_nms(g, fs->p, B, s);
       else if (nm == "hysteresis") launch_hyst(g, fs->p, B, s);
       else if (nm == "k_fill") launch_fill(g, fs->p, B, s);
-      else if (nm == "k_tile_count" || nm == "k_pts_tiles") launch_tile_points(g, fs->p, B, s, st[i].w);
+      else if (nm == "k_tile_count" || nm == "k_pts_tiles") launch_tile_points(gp, fs->p, B, s, st[i].w);
       else launch_keyframe(g, fs->p, 0, 2, b->n_pairs, s, st[i].w);
       HIPCHECK(hipGetLastError());
       HIPCHECK(hipEventRecord(ev[i + 1], s));

@@ -96,10 +96,19 @@ __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ 
 // depth half (78.6 of the 98 MB the level-1 launch reads) only feeds the edge lists.  A batch build that leaves its edge lists
 // to the first consumer (REVO_DEFER >= 2) launches the gray half alone and leaves the depth half to that consumer as well
 // (run_pending_edt): same threads, same arithmetic, same bits, two launches.  The single-frame API keeps the fused launch.
-template <bool GRAY, bool DEPTH>
+// Staging of the source level's edge depths (depth half of a pipelined batch, edges final): see k_edge_prefix / k_pts_tiles.
+struct EdgeStage {
+  const uint2* cs;              // source level's bitmaps, .y = the final edge bitmap (frame stride sh * wpr)
+  const unsigned short* epre;   // edge pixels of the rows above inside the tile, per (row, word column)
+  const int* base;              // first staging position of the level's tiles (this level's slice of stage_base), frame stride tiles_total
+  float* out;                   // staged depths (frame stride sw * sh)
+  int wpr, tiles_total;         // words per row of the source level; tiles of all levels (frame stride of base)
+};
+template <bool GRAY, bool DEPTH, bool STAGE = false>
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
                                                  int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst, int frame0,
-                                                 uint8_t* __restrict__ vsrc, float dmin, float dmax) {
+                                                 uint8_t* __restrict__ vsrc, float dmin, float dmax, EdgeStage es) {
+  static_assert(!STAGE || DEPTH, "staging rides on the depth half");
   const int f = frame0 + blockIdx.z;
   src += (size_t)f * sw * sh;
   dst += (size_t)f * dw * dh;
@@ -168,6 +177,27 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src
     }
     vsrc[(size_t)(2 * (oy + q)) * (sw >> 3) + gx] = (uint8_t)vt;
     vsrc[(size_t)(2 * (oy + q) + 1) * (sw >> 3) + gx] = (uint8_t)vbm;
+    if (STAGE) {
+      // the eight pixels of each of the two source rows held here: those that are EDGE pixels leave their depth at
+      // base(tile) + edge pixels of the tile's rows above (epre) + edge pixels in front of them in this row's word
+      const int wc = (8 * gx) >> 5, sh8 = (8 * gx) & 31;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int y = 2 * (oy + q) + rr;
+        const uint32_t E = es.cs[((size_t)f * sh + y) * es.wpr + wc].y;
+        uint32_t eb = (E >> sh8) & 0xffu;
+        if (eb) {
+          const int tile = (y >> 5) * es.wpr + wc;
+          int pos = es.base[(size_t)f * es.tiles_total + tile] + (int)es.epre[((size_t)f * sh + y) * es.wpr + wc] +
+                    __popc(E & ((1u << sh8) - 1u));
+          float* o = es.out + (size_t)f * sw * sh;
+          const float* row = rr ? bot : top;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if ((eb >> k) & 1u) o[pos++] = row[k];
+        }
+      }
+    }
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1633,6 +1663,68 @@ __device__ __forceinline__ int level_tile_base(const PyrGeom& g, int l) {  // ti
   return b;
 }
 
+// Where the depth half of k_pyrdown stages the depths of a level's EDGE pixels (levels below the coarsest; batches whose depth
+// pyramid runs behind Canny): tiles in raster order, rows of a tile top to bottom, pixels of a row left to right -- the order of
+// the tile-ordered list, over ALL edge pixels (the depth test comes later: it needs the depths).  One workgroup per
+// (level, frame), half a wavefront per tile, lane = row: the row's edge count, its prefix inside the tile (epre), the tile's
+// total, an exclusive scan over the level's tiles (stage_base).  Bitmaps only: ~3 MB read, ~1.3 MB written per 64 frames.
+__global__ void __launch_bounds__(1024) k_edge_prefix(PyrGeom g, FramePlanes pl) {
+  __shared__ int s_tile[2048];
+  __shared__ int s_wsum[16];
+  const int nL = g.n_levels - 1;
+  const int nB = gridDim.x / nL;
+  const int l = blockIdx.x / nB;
+  const int f = g.frame0 + blockIdx.x % nB;
+  const LevelGeom& lv = g.lv[l];
+  const int wpr = lv.wpr, h = lv.h, ntiles = wpr * lv.nchunk;
+  const uint2* csw = pl.cs[l] + (size_t)f * h * wpr;
+  unsigned short* epre = pl.epre[l] + (size_t)f * h * wpr;
+  const int tid = threadIdx.x, r = tid & 31;
+  for (int i = tid; i < ntiles; i += 1024) s_tile[i] = 0;
+  __syncthreads();
+  for (int t0 = tid >> 5; t0 < ntiles; t0 += 4 * 32) {  // four tiles per trip, like k_tile_count
+    uint32_t E[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + 32 * q;
+      const int c = t / wpr, wc = t - c * wpr, y = c * 32 + r;
+      E[q] = (t < ntiles && y < h) ? csw[(size_t)y * wpr + wc].y : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + 32 * q;
+      const int c = t / wpr, wc = t - c * wpr, y = c * 32 + r;
+      const int cnt = __popc(E[q]);
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const int u = __shfl_up(incl, o, 32);
+        if (r >= o) incl += u;
+      }
+      if (t < ntiles && y < h) epre[(size_t)y * wpr + wc] = (unsigned short)(incl - cnt);
+      if (r == 31 && t < ntiles) s_tile[t] = incl;
+    }
+  }
+  __syncthreads();
+  const int i0 = 2 * tid, i1 = 2 * tid + 1;
+  const int c0 = i0 < ntiles ? s_tile[i0] : 0, c1 = i1 < ntiles ? s_tile[i1] : 0;
+  int incl = c0 + c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += u;
+  }
+  if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+  __syncthreads();
+  int pre = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pre += k < (tid >> 6) ? s_wsum[k] : 0;
+  const int ex = pre + incl - (c0 + c1);
+  int* sb = pl.stage_base + (size_t)f * g.total_tiles + level_tile_base(g, l);
+  if (i0 < ntiles) sb[i0] = ex;
+  if (i1 < ntiles) sb[i1] = ex + c0;
+}
+
 __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) {
   __shared__ int s_tile[2048];   // per tile: count, then exclusive base (levels up to 2048 x 1024: 64 x 32 tiles)
   __shared__ int s_wsum[16];
@@ -1708,6 +1800,7 @@ __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) 
 // through LDS took 33 us alone but 120 us in the pipelined step).
 __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
   __shared__ unsigned short s_src[PT_TILES][1024];  // list position inside the tile -> (row << 5 | column)
+  __shared__ unsigned short s_esrc[PT_TILES][1024]; // ... -> position among the tile's EDGE pixels (staged depths)
   // 1-D grid, frame fastest (the tile groups of a frame share one XCD's L2)
   const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
   const int nB = gridDim.x / groups;
@@ -1746,19 +1839,44 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
   const int total = __shfl(incl, 31, 32);
   if (total == 0) return;  // (half-wave uniform)
   unsigned short* src = s_src[threadIdx.x >> 5];
+  // staged depths (g.pts_staged, levels with validity bits): the depth of the tile's k-th EDGE pixel (row-major, valid or not)
+  // sits at stage[stage_base(tile) + k] -- a few consecutive lines per tile instead of every line of the plane that holds a point
+  const bool staged = g.pts_staged && has_vb;
+  unsigned short* esrc = s_esrc[threadIdx.x >> 5];
   {
     int o = incl - cnt;
-    for (uint32_t m = v; m; m &= m - 1, ++o) src[o] = (unsigned short)((r << 5) | (__ffs(m) - 1));
+    int ebase = 0;
+    if (staged) {  // edge pixels of the rows above in this tile (the scan k_edge_prefix did: recomputed, it is five exchanges)
+      const int ec = __popc(E);
+      int ei = ec;
+#pragma unroll
+      for (int q = 1; q < 32; q <<= 1) {
+        const int u = __shfl_up(ei, q, 32);
+        if (r >= q) ei += u;
+      }
+      ebase = ei - ec;
+    }
+    for (uint32_t m = v; m; m &= m - 1, ++o) {
+      const int b = __ffs(m) - 1;
+      src[o] = (unsigned short)((r << 5) | b);
+      if (staged) esrc[o] = (unsigned short)(ebase + __popc(E & ((1u << b) - 1u)));
+    }
   }
   // (the half-wave reads what it wrote itself: program order within the wave is enough)
   float4* out = pl.pts_trk[l] + (size_t)f * lv.npix + tile_first;
+  const float* stage_t = staged ? pl.stage[l] + (size_t)f * lv.npix + pl.stage_base[(size_t)f * g.total_tiles + tg] : nullptr;
   for (int k0 = r; k0 < total; k0 += 4 * 32) {  // four positions per lane and trip: their gathers are in flight together
     int rb[4];
     float Z[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) rb[q] = k0 + 32 * q < total ? (int)src[k0 + 32 * q] : -1;
+    if (staged) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Z[q] = rb[q] >= 0 ? depth[(size_t)(y0 + (rb[q] >> 5)) * w + x0 + (rb[q] & 31)] : 0.0f;
+      for (int q = 0; q < 4; ++q) Z[q] = rb[q] >= 0 ? stage_t[esrc[k0 + 32 * q]] : 0.0f;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Z[q] = rb[q] >= 0 ? depth[(size_t)(y0 + (rb[q] >> 5)) * w + x0 + (rb[q] & 31)] : 0.0f;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (rb[q] < 0) continue;
@@ -2107,15 +2225,28 @@ void launch_gray_depth(const PyrGeom& g, const FramePlanes& p, const uint8_t* d_
                      p.depth[0], npix, g.frame0);
 }
 
-void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s, int parts) {
+void launch_pyrdown(const PyrGeom& g, const FramePlanes& p, int lvl, int B, hipStream_t s, int parts, bool stage_edges) {
   const LevelGeom& d = g.lv[lvl];
   const LevelGeom& sl = g.lv[lvl - 1];
   dim3 grid(((d.w / 4) * ((d.h + 1) / 2) + 255) / 256, 1, B);
-#define PYRDOWN_ARGS p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h, p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max
+  EdgeStage es{};
+  if (stage_edges) {
+    int tb = 0;
+    for (int k = 0; k < lvl - 1; ++k) tb += g.lv[k].wpr * g.lv[k].nchunk;
+    es.cs = p.cs[lvl - 1]; es.epre = p.epre[lvl - 1]; es.base = p.stage_base + tb; es.out = p.stage[lvl - 1];
+    es.wpr = sl.wpr; es.tiles_total = g.total_tiles;
+  }
+#define PYRDOWN_ARGS p.gray[lvl - 1], sl.w, sl.h, p.gray[lvl], d.w, d.h, p.depth[lvl - 1], p.depth[lvl], g.frame0, p.vb[lvl - 1], g.depth_min, g.depth_max, es
   if (parts == 1) hipLaunchKernelGGL((k_pyrdown<true, false>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
+  else if (parts == 2 && stage_edges) hipLaunchKernelGGL((k_pyrdown<false, true, true>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
   else if (parts == 2) hipLaunchKernelGGL((k_pyrdown<false, true>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
   else hipLaunchKernelGGL((k_pyrdown<true, true>), grid, dim3(256), 0, s, PYRDOWN_ARGS);
 #undef PYRDOWN_ARGS
+}
+
+void launch_edge_prefix(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
+  if (g.n_levels < 2) return;
+  hipLaunchKernelGGL(k_edge_prefix, dim3((g.n_levels - 1) * B), dim3(1024), 0, s, g, p);
 }
 
 void launch_canny_nms(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {

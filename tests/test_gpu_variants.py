@@ -134,6 +134,48 @@ def test_mixed_and_single_hysteresis_agree_on_the_bench_frames(api, monkeypatch)
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("size,levels", [((640, 480), 4), ((320, 240), 3), ((160, 120), 3)])
+def test_staged_edge_depths_give_the_same_lists(api, ro, monkeypatch, size, levels):
+    """Round 6: in a pipelined batch the depth half of pyrDown runs behind Canny, so it also stages the
+    depths of the level's EDGE pixels in list order (k_edge_prefix + k_pyrdown<.., STAGE>), and k_pts_tiles reads those instead
+    of gathering from the depth planes.  Same points, same order, same bits as with REVO_STAGE_EDGE_DEPTHS=0 -- on the Canny /
+    depth edge cases (NaN, inf, holes, dense noise, fill-in) and on rendered pairs -- and the reference-ordered accessor list
+    still equals the oracle's (imgpyramidrgbd.cpp:199-226)."""
+    import torch
+    w, h = size
+    hp = (20, 10, 5, 0, 0, 0) if w == 640 else ((10, 5, 0, 0, 0, 0) if w == 320 else (5, 0, 0, 0, 0, 0))
+    s = ImgPyramidSettings.scaled(w, h, levels, hist_patch=hp)
+    frames = [(bgr, depth) for _, bgr, depth in _edge_cases(s)]
+    for i in range(2):
+        p = synth.make_pair(40 + i, s)
+        frames += [p["ref"], p["curr"]]
+    if len(frames) % 2:
+        frames.append(frames[0])
+    n = len(frames) // 2
+    bgr = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    dep = torch.from_numpy(np.stack([f[1] for f in frames]).astype(np.float32)).cuda()
+    got = {}
+    for stage in ("1", "0"):
+        monkeypatch.setenv("REVO_STAGE_EDGE_DEPTHS", stage)
+        cam = api.CameraPyr(s)
+        api.TrackerNew(TrackerSettings(), s, cam)
+        bt = api.BatchTracker(cam, n)
+        res = torch.zeros(n * 96, dtype=torch.uint8, device="cuda")
+        bt.track(bgr.data_ptr(), dep.data_ptr(), res.data_ptr())
+        bt.sync()
+        lists = [bt.frame(f, s).edges3DTiled(lvl).copy() for f in range(2 * n) for lvl in range(levels)]
+        got[stage] = (res.cpu().numpy().tobytes(), lists)
+        if stage == "1":  # the accessor's list (built on demand from the planes) against the oracle, frame by frame
+            for f in (0, 1, 2 * n - 1):
+                o = ro.Pyramid(s, frames[f][0], frames[f][1])
+                for lvl in range(levels):
+                    assert np.array_equal(bt.frame(f, s).return3DEdges(lvl), o.read(6, lvl), equal_nan=True)
+    assert sum(len(x) for x in got["1"][1]) > 1000
+    for a, b in zip(got["1"][1], got["0"][1]):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), "tile-ordered list differs"
+    assert got["1"][0] == got["0"][0], "tracker records differ"
+
+
 def test_tracker_tolerance_distribution_128_pairs(api, ro, capsys):
     """The soak tool's statement as a test: 128 seeded 640x480 / 4-level pairs through bench-sized batches (32 pairs, the
     bench's cluster shape) against the oracle, pair by pair -- TWICE:
