@@ -11,7 +11,7 @@ acc = collections.OrderedDict()
 for n, s, e in rows:
     if "k_track" in n or "rocclr" in n or "at::" in n:
         continue
-    key = n.split("::")[-1].split("(")[0]
+    key = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     ov = any(s < te and e > ts for ts, te in tr)
     acc.setdefault(key, [[], []])[1 if ov else 0].append((e - s) / 1e3)
 print("k_track avg %.0f us over %d launches" % (sum(e - s for s, e in tr) / len(tr) / 1e3, len(tr)))

@@ -12,7 +12,7 @@ kn = "kernel_name" if "kernel_name" in cols else "name"
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for k, c, v, d in db.execute("select %s, counter_name, value, dispatch_id from counters_collection" % kn):
-    short = k.split("::")[-1].split("(")[0]
+    short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     if want and not any(w in short for w in want):
         continue
     acc[short][c] += v

@@ -32,7 +32,7 @@ def per_kernel(path, counter):
     for k, c, v, d in db.execute("select %s, counter_name, value, dispatch_id from counters_collection" % kn):
         if c != counter:
             continue
-        short = k.split("::")[-1].split("(")[0]
+        short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         acc[short] += v
         cnt[short].add(d)
     return {k: acc[k] / len(cnt[k]) for k in acc}

@@ -8,7 +8,7 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 sid = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "0")
 rows = list(db.execute("select name, start, end, %s from kernels order by start" % sid))
-short = lambda n: n.split("::")[-1].split("(")[0].split("<")[0]
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
 trk = [i for i, r in enumerate(rows) if "k_track<true>" in r[0] or "k_trackILb1" in r[0]]
 first = int(sys.argv[2]) if len(sys.argv) > 2 else len(trk) // 2
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4

@@ -7,7 +7,7 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 sid = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
 rows = list(db.execute("select name, start, end, %s from kernels order by start" % (sid or "0")))
-short = lambda n: n.split("::")[-1].split("(")[0]
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 gray = [i for i, r in enumerate(rows) if "k_gray_depth" in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(gray) - 3
 i0, i1 = gray[k], gray[k + 1]

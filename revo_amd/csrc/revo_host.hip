@@ -110,7 +110,7 @@ struct Knobs {
   int h2d_mode;        // REVO_H2D_STREAMS: 0 = colour and depth planes on two copy streams, 1 = one stream, 2 = swapped
   int direct_h2d;      // REVO_DIRECT_H2D (default 1): revo_pyramid_create reads page-locked caller rows in place (no staging copy)
   int h2d_max_run_mb;  // REVO_H2D_MAX_RUN_MB: host-buffer batches merge adjacent frames into copies of at most this many MB
-  int stage_edge_depths;  // REVO_STAGE_EDGE_DEPTHS (default 1): pipelined batches stage the edge pixels' depths in the depth pass
+  int stage_edge_depths;  // REVO_STAGE_EDGE_DEPTHS (default 0): pipelined batches stage the edge pixels' depths in the depth pass
 };
 
 struct revo_ctx {
@@ -559,7 +559,7 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   c->knobs.redundant_one = env_int("REVO_TRACK_REDUNDANT_ONE", 1024, 0, 1 << 30);
   c->knobs.h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
   c->knobs.direct_h2d = env_int("REVO_DIRECT_H2D", 1, 0, 1);
-  c->knobs.stage_edge_depths = env_int("REVO_STAGE_EDGE_DEPTHS", 1, 0, 1);
+  c->knobs.stage_edge_depths = env_int("REVO_STAGE_EDGE_DEPTHS", 0, 0, 1);  // built, bit-exact, 80 MB less traffic per step and 2.6 % SLOWER: off (profiles/r06_ab_stage_edge_depths.txt)
   c->knobs.h2d_max_run_mb = env_int("REVO_H2D_MAX_RUN_MB", 64, 1, 4096);  // (profiles/r06_h2d_run_sizes.txt: 2 / 8 / 24 / 64 MB / unbounded)
   if (opt) c->os = *opt; else revo_opt_settings_default(&c->os);
   if (trk) c->ts = *trk; else revo_tracker_settings_default(&c->ts);
@@ -690,7 +690,10 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
       // ... and the edges are final by now, so the depth pass -- which streams every depth of a level anyway -- also leaves the
       // depths of the level's EDGE pixels behind, compact and in list order (k_edge_prefix tells it where): the edge-list
       // write then reads ~10 MB of staged depths instead of every 128-byte line of the depth planes that holds an edge
-      // pixel (~100 MB per 64-frame batch).  REVO_STAGE_EDGE_DEPTHS=0: gather from the planes as before.
+      // pixel (~100 MB per 64-frame batch).  Measured (profiles/r06_ab_stage_edge_depths.txt): k_pts_tiles
+      // moves 61 MB instead of 141 (1.09x its algorithmic bytes), the step 72 MB less -- and is 2.6 % SLOWER: 2.3 M scattered
+      // 4-byte stores and the prefix kernel cost the depth pass more time than the sparse line reads they replace, and no kernel
+      // of this chain is bandwidth-bound.  Bit-exact, OFF by default (REVO_STAGE_EDGE_DEPTHS=1 turns it on).
       const bool stage = c->knobs.stage_edge_depths && fs->p.stage[0] != nullptr && c->geom.n_levels > 1;
       if (stage) launch_edge_prefix(c->geom, fs->p, fs->B, s);
       for (int l = 1; l < c->geom.n_levels; ++l) launch_pyrdown(c->geom, fs->p, l, fs->B, s, 2, stage);
