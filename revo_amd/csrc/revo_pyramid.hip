@@ -20,6 +20,14 @@
 
 namespace {
 
+// experiment knob (compile time, profiles/build_var.sh): instruction-issue priority of the build stream's kernels -- the build
+// stream is the busiest of the pipelined step's four and its kernels run next to tracker waves on every CU
+#ifdef REVO_BUILD_PRIO
+#define BUILD_PRIO() __builtin_amdgcn_s_setprio(REVO_BUILD_PRIO)
+#else
+#define BUILD_PRIO()
+#endif
+
 __device__ __forceinline__ int level_of(const PyrGeom& g, int v, int LevelGeom::*base) {
   int l = 0;
 #pragma unroll
@@ -55,6 +63,7 @@ __device__ __forceinline__ uint32_t gray4(uint32_t a, uint32_t b, uint32_t c) {
 __global__ void __launch_bounds__(256) k_gray_depth(const uint8_t* __restrict__ bgr, const float* __restrict__ depth_f32,
                                                     const uint16_t* __restrict__ depth_u16, float alpha,
                                                     uint8_t* __restrict__ gray, float* __restrict__ depth_out, int npix, int frame0) {
+  BUILD_PRIO();
   const int f = frame0 + blockIdx.z;
   const int g16 = blockIdx.x * 256 + threadIdx.x;
   if (g16 * 16 >= npix) return;
@@ -108,6 +117,7 @@ template <bool GRAY, bool DEPTH, bool STAGE = false>
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
                                                  int dw, int dh, const float* __restrict__ dsrc, float* __restrict__ ddst, int frame0,
                                                  uint8_t* __restrict__ vsrc, float dmin, float dmax, EdgeStage es) {
+  BUILD_PRIO();
   static_assert(!STAGE || DEPTH, "staging rides on the depth half");
   const int f = frame0 + blockIdx.z;
   src += (size_t)f * sw * sh;
@@ -310,6 +320,7 @@ __device__ __forceinline__ void nms_row4(const MRow4& A, const MRow4& B, const M
   *strong = sb;
 }
 __global__ void __launch_bounds__(256) k_canny_nms4(PyrGeom g, FramePlanes pl) {
+  BUILD_PRIO();
   const int f = g.frame0 + blockIdx.z;
   if (blockIdx.x == 0 && threadIdx.x < REVO_L) {  // per-frame words the banded hysteresis accumulates into / raises
     pl.need_full[f * REVO_L + threadIdx.x] = 0;
@@ -865,6 +876,7 @@ __device__ __forceinline__ void hyst_level(const PyrGeom& g, const FramePlanes& 
 // frames/s; a 512-thread, 144 KB variant that fits next to a tracker workgroup: 72 k, the kernel alone is 35 % slower.)
 template <bool C_IN_LDS, bool E_GLOBAL = false>
 __global__ void __launch_bounds__(HYST_THREADS) k_hyst(PyrGeom g, FramePlanes pl, int only_flagged, int n_frames) {
+  BUILD_PRIO();
   extern __shared__ uint32_t s_mem[];
   const int n_items = g.n_levels * n_frames;
   if (only_flagged) {  // one parallel sweep over the flags: normally nothing is flagged and the launch ends here
@@ -1386,6 +1398,7 @@ __global__ void __launch_bounds__(HO_THREADS) k_hyst_out(PyrGeom g, FramePlanes 
 // gridDim.x workgroups per frame share its pixels (large images: one block per frame took 205 us of a 1.19 ms build at
 // 1280x960, where the bench frames do open the gate; the launcher then enqueues the levels one after the other).
 __global__ void __launch_bounds__(1024) k_fill(PyrGeom g, FramePlanes pl, int only_level) {
+  BUILD_PRIO();
   const int f = g.frame0 + blockIdx.z;
   const int la = only_level ? only_level : 1, lb = only_level ? only_level + 1 : g.n_levels;
   for (int l = la; l < lb; ++l) {
@@ -1798,9 +1811,12 @@ __global__ void __launch_bounds__(1024) k_tile_count(PyrGeom g, FramePlanes pl) 
 // consecutive lanes write consecutive 16-byte entries.  No depth staging, ~32 VGPRs, 2 KB of LDS per tile: the kernel
 // keeps its occupancy next to the trackers and the EDT it runs beside (the round-3 version that staged 4 KB depth tiles
 // through LDS took 33 us alone but 120 us in the pipelined step).
+// STAGED (a template parameter, not a run-time flag: its second 16 KB table would halve the plain kernel's workgroups per CU --
+// measured: 40 -> 90 us in the pipelined step): the depths come from FramePlanes::stage (k_edge_prefix / k_pyrdown<.., STAGE>)
+template <bool STAGED>
 __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePlanes pl) {
   __shared__ unsigned short s_src[PT_TILES][1024];  // list position inside the tile -> (row << 5 | column)
-  __shared__ unsigned short s_esrc[PT_TILES][1024]; // ... -> position among the tile's EDGE pixels (staged depths)
+  __shared__ unsigned short s_esrc[STAGED ? PT_TILES : 1][STAGED ? 1024 : 1]; // ... -> position among the tile's EDGE pixels (staged depths)
   // 1-D grid, frame fastest (the tile groups of a frame share one XCD's L2)
   const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
   const int nB = gridDim.x / groups;
@@ -1841,8 +1857,8 @@ __global__ void __launch_bounds__(32 * PT_TILES) k_pts_tiles(PyrGeom g, FramePla
   unsigned short* src = s_src[threadIdx.x >> 5];
   // staged depths (g.pts_staged, levels with validity bits): the depth of the tile's k-th EDGE pixel (row-major, valid or not)
   // sits at stage[stage_base(tile) + k] -- a few consecutive lines per tile instead of every line of the plane that holds a point
-  const bool staged = g.pts_staged && has_vb;
-  unsigned short* esrc = s_esrc[threadIdx.x >> 5];
+  const bool staged = STAGED && has_vb;
+  unsigned short* esrc = s_esrc[STAGED ? (threadIdx.x >> 5) : 0];
   {
     int o = incl - cnt;
     int ebase = 0;
@@ -2346,7 +2362,8 @@ void launch_fill(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
 void launch_tile_points(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s, int which) {
   if (which & 1) hipLaunchKernelGGL(k_tile_count, dim3(g.n_levels * B), dim3(1024), 0, s, g, p);
   const int groups = (g.total_tiles + PT_TILES - 1) / PT_TILES;
-  if (which & 2) hipLaunchKernelGGL(k_pts_tiles, dim3(groups * B), dim3(32 * PT_TILES), 0, s, g, p);
+  if ((which & 2) && g.pts_staged) hipLaunchKernelGGL(k_pts_tiles<true>, dim3(groups * B), dim3(32 * PT_TILES), 0, s, g, p);
+  else if (which & 2) hipLaunchKernelGGL(k_pts_tiles<false>, dim3(groups * B), dim3(32 * PT_TILES), 0, s, g, p);
 }
 
 void launch_compact(const PyrGeom& g, const FramePlanes& p, int B, hipStream_t s) {
