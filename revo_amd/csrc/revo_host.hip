@@ -86,6 +86,7 @@ struct FrameSet {
   bool pts_pending = false;       // (REVO_DEFER >= 2) the tile-ordered edge lists of ALL frames were left to the same consumer too
   bool depth_pending = false;     // ... and the build ran only the gray half of pyrDown: the depth half goes in front of the lists
   bool hyst_pending = false;      // (REVO_DEFER = 3) ... and hysteresis + fill-in: the build stopped behind the Canny NMS
+  bool fill_pending = false;      // (REVO_DEFER = 2, REVO_DEFER_FILL) ... fill-in alone: the build stopped behind the hysteresis
   // whoever ran the deferred EDT recorded this on ITS stream: consumers (and the next build into these planes) on any other
   // stream order themselves behind it (`edt_pending == false` alone says "enqueued somewhere", not "visible here")
   hipEvent_t ev_edt = nullptr;
@@ -174,6 +175,7 @@ struct revo_batch {
   int cluster;
   int defer = 2;                   // REVO_DEFER / REVO_EDT_DEFER, read when the batch is created (env_defer_level)
   int split_depth = 1;             // REVO_SPLIT_DEPTH (default 1): with the lists deferred, the depth half of the pyramid is deferred with them
+  int defer_fill = 0;              // REVO_DEFER_FILL: with the lists deferred, fill-in is deferred with them
   hipStream_t stream;
   hipStream_t side = nullptr;                      // the EDT of the keyframes runs here, next to the edge lists
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -520,7 +522,8 @@ static void frameset_destroy(FrameSet* fs) {
 // with_points = false: stops after fillInEdges; the caller enqueues launch_tile_points itself (batches run it next to the EDT)
 static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const float* d_depth_f32,
                           const uint16_t* d_depth_u16, float alpha, hipStream_t s, bool borrow_depth = false,
-                          bool with_points = true, int frame0 = 0, int nframes = -1, bool with_hyst = true, bool gray_only = false) {
+                          bool with_points = true, int frame0 = 0, int nframes = -1, bool with_hyst = true, bool gray_only = false,
+                          bool with_fill = true) {
   PyrGeom g = c->geom;
   g.frame0 = frame0;
   const int B = nframes < 0 ? fs->B : nframes;
@@ -531,7 +534,7 @@ static void enqueue_build(revo_ctx* c, FrameSet* fs, const uint8_t* d_bgr, const
   launch_canny_nms(g, fs->p, B, s);
   if (!with_hyst) return;  // (batches with REVO_DEFER = 3: the rest is left to the first consumer, run_pending_edt)
   launch_hyst(g, fs->p, B, s);
-  launch_fill(g, fs->p, B, s);
+  if (with_fill) launch_fill(g, fs->p, B, s);  // (pipelined batches may leave it to the first consumer: only the edge lists and the EDT read its result)
   if (with_points) launch_tile_points(g, fs->p, B, s);  // the tracker's (tile-ordered) edge list; the reference's order is built on demand
 }
 
@@ -678,7 +681,8 @@ static int run_pending_edt(revo_ctx* c, FrameSet* fs, hipStream_t s) {
     return REVO_OK;
   }
   if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, fs->ev_ready, 0));
-  if (fs->hyst_pending) { launch_hyst(c->geom, fs->p, fs->B, s); launch_fill(c->geom, fs->p, fs->B, s); fs->hyst_pending = false; }
+  if (fs->hyst_pending) { launch_hyst(c->geom, fs->p, fs->B, s); launch_fill(c->geom, fs->p, fs->B, s); fs->hyst_pending = false; fs->fill_pending = false; }
+  if (fs->fill_pending) { launch_fill(c->geom, fs->p, fs->B, s); fs->fill_pending = false; }
   // (the edge lists and the EDT do not depend on each other; running the EDT first -- next to the memory-bound first kernels of
   // the following build instead of its VALU-bound NMS -- was measured equal: profiles/r04_ab_aux_order.txt)
   if (fs->pts_pending) {
@@ -1295,6 +1299,7 @@ extern "C" int revo_batch_create(revo_ctx* c, int n_pairs, revo_batch** out) {
   b->cluster = pick_cluster(c, n_pairs);
   b->defer = env_defer_level();
   b->split_depth = env_int("REVO_SPLIT_DEPTH", 1, 0, 1);
+  b->defer_fill = env_int("REVO_DEFER_FILL", 0, 0, 1);
   HIPCHECK(hipMalloc((void**)&b->d_mail, mail_bytes(n_pairs, b->cluster)));
   HIPCHECK(hipMemset(b->d_mail, 0, mail_bytes(n_pairs, b->cluster)));
   for (int f = 0; f < 2 * n_pairs; ++f) b->views.push_back(revo_pyr{c, b->fs, f, false, (f % 2) == 0, 0.0, false, false});
@@ -1351,6 +1356,9 @@ static int batch_mark_tracker(revo_batch* b, hipStream_t s) {
 // the depth half of the pyramid travels with the deferred edge lists (REVO_DEFER >= 2, no side stream; REVO_SPLIT_DEPTH=0 keeps it
 // in the build: an experiment knob read when the batch is created)
 static bool batch_splits_depth(const revo_batch* b) { return !b->side && b->defer >= 2 && b->split_depth; }
+// fillInEdges travels with the deferred work too (REVO_DEFER = 2, REVO_DEFER_FILL: read when the batch is created): nothing on the
+// build stream reads its result -- the next kernels of that stream belong to the NEXT build
+static bool batch_defers_fill(const revo_batch* b) { return !b->side && b->defer == 2 && b->defer_fill; }
 static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
   const PyrGeom& g = b->ctx->geom;
   if (b->side) {
@@ -1373,6 +1381,7 @@ static int enqueue_batch_tail(revo_batch* b, hipStream_t s) {
     if (lvl < 2) launch_tile_points(g, b->fs->p, b->fs->B, s);
     std::lock_guard<std::mutex> lk(b->fs->edt_mu);
     b->fs->hyst_pending = lvl >= 3;
+    b->fs->fill_pending = batch_defers_fill(b);
     b->fs->pts_pending = lvl >= 2;
     b->fs->depth_pending = batch_splits_depth(b);
     b->fs->edt_pending = true; b->fs->edt_count = b->n_pairs;
@@ -1396,7 +1405,8 @@ static int batch_build_f32(revo_batch* b, const uint8_t* d_bgr, const float* d_d
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }     // ... or its deferred EDT, on whichever stream ran it
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }              // ... and its tracker grid still reads lists and DT planes
   // (Measured and not kept: the two halves of the batch as two concurrent kernel chains -- 78.4 k -> 70.5 k frames/s.)
-  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || b->defer < 3, batch_splits_depth(b));
+  enqueue_build(b->ctx, b->fs, d_bgr, d_depth, nullptr, 0.f, s, borrow, false, 0, -1, b->side || b->defer < 3, batch_splits_depth(b),
+                !batch_defers_fill(b));
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
@@ -1478,7 +1488,7 @@ extern "C" int revo_batch_build_u16(revo_batch* b, const uint8_t* d_bgr, const u
   { int rc = wait_edt_before_rebuild(b->fs, s); if (rc) return rc; }
   { int rc = batch_wait_tracker(b, s); if (rc) return rc; }
   enqueue_build(b->ctx, b->fs, d_bgr, nullptr, d_depth_raw, (float)(1.0f / depth_scale_factor), s, false, false, 0, -1,
-                b->side || b->defer < 3, batch_splits_depth(b));
+                b->side || b->defer < 3, batch_splits_depth(b), !batch_defers_fill(b));
   { int rc = enqueue_batch_tail(b, s); if (rc) return rc; }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(b->fs->ev_ready, s));  // accessors / single-pair calls on the batch's views wait for this
@@ -1797,7 +1807,7 @@ extern "C" int revo_batch_profile_build(revo_batch* b, const uint8_t* d_bgr, con
   }
   {  // the state a build + prepare leaves behind
     std::lock_guard<std::mutex> lk(fs->edt_mu);
-    fs->edt_pending = false; fs->pts_pending = false; fs->depth_pending = false; fs->hyst_pending = false;
+    fs->edt_pending = false; fs->pts_pending = false; fs->depth_pending = false; fs->hyst_pending = false; fs->fill_pending = false;
     HIPCHECK(hipEventRecord(fs->ev_edt, s));
     fs->has_edt = true; fs->edt_stream = s;
   }
