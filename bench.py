@@ -751,7 +751,7 @@ def main():
     # sources is NOT quoted (the constant must not go stale silently).
     traffic, traffic_src, traffic_commit = None, None, None
     src_now = kernel_sha16()
-    for pmc_name in ("r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest committed pass of this workload
+    for pmc_name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest committed pass of this workload
         pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_file) and a.pairs == 32 and a.width == 640 and a.levels == 4:
             try:
