@@ -12,9 +12,10 @@ short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").
 trk = [i for i, r in enumerate(rows) if "k_track<true>" in r[0] or "k_trackILb1" in r[0]]
 first = int(sys.argv[2]) if len(sys.argv) > 2 else len(trk) // 2
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+count = int(sys.argv[4]) if len(sys.argv) > 4 else 100  # launches the statistics cover (stay inside ONE run of the driver)
 q_trk = rows[trk[first]][3]
 per = []
-for k in range(first, min(first + 100, len(trk) - 1)):  # (the io_thread run of single_stream_profile.py: 119 launches behind a warm-up of 5)
+for k in range(first, min(first + count, len(trk) - 1)):
     per.append((rows[trk[k + 1]][1] - rows[trk[k]][1]) / 1e3)
 import statistics
 print("frames %d..%d: k_track start to next k_track start: median %.1f us (min %.1f, max %.1f); k_track duration median %.1f us"
