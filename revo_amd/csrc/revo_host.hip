@@ -93,8 +93,9 @@ struct FrameSet {
   hipStream_t edt_stream = nullptr;
   bool has_edt = false;
   hipEvent_t ev_free = nullptr;   // recorded on the tracker stream when the set goes back to the pool
+  hipEvent_t ev_free2 = nullptr;  // ... and on the vote stream (the quality vote and the cloud copy read the set there)
   hipEvent_t ev_h2d = nullptr;    // (single-frame API) the copy out of page-locked caller rows has finished
-  bool has_ready = false, has_free = false;
+  bool has_ready = false, has_free = false, has_free2 = false;
 };
 
 struct Past {  // one entry of mPastPcl / mPastWorldPoses / mPastTimeStamps (tracker.h:92-95)
@@ -146,6 +147,11 @@ struct revo_ctx {
   // host-buffer batches (revo_track_pairs_*): up to 3 jobs in flight, slots recycled per (n, depth type)
   std::vector<struct revo_pairs_job*> jobs;
   hipStream_t copy_stream = nullptr, copy_stream2 = nullptr, pair_streams[2] = {nullptr, nullptr};
+  // The quality vote and the past-cloud copies run on a stream of their own (REVO_VOTE_STREAM=0: on the tracker stream, as up
+  // to round 5): nothing the NEXT frame's tracker reads comes out of them, so in the sequential loop tracker N+1 follows
+  // tracker N directly instead of queueing behind vote N and copy N-1 (profiles/r06_single_stream_timeline.txt: ~35 us of 240).
+  hipStream_t vote_stream = nullptr;
+  hipEvent_t ev_vote = nullptr;
   hipStream_t frame_copy_stream = nullptr;  // single-frame API: H2D straight out of page-locked caller rows (pyramid_create_common)
   unsigned long long jobs_submitted = 0;
   // coloured point cloud (generateColoredPcl), allocated on first use
@@ -496,6 +502,7 @@ static int frameset_create(revo_ctx* c, int B, bool with_staging, FrameSet** out
   }
   HIPCHECK(hipEventCreateWithFlags(&fs->ev_ready, hipEventDisableTiming));
   HIPCHECK(hipEventCreateWithFlags(&fs->ev_free, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&fs->ev_free2, hipEventDisableTiming));
   HIPCHECK(hipEventCreateWithFlags(&fs->ev_edt, hipEventDisableTiming));
   // counts start at zero so an accessor on a not-yet-built pyramid is well defined
   hipMemsetAsync(fs->p.npts, 0, sizeof(int) * REVO_L * B, c->stream);
@@ -510,6 +517,7 @@ static void frameset_destroy(FrameSet* fs) {
   if (fs->h_depth) hipHostFree(fs->h_depth);
   if (fs->ev_ready) hipEventDestroy(fs->ev_ready);
   if (fs->ev_free) hipEventDestroy(fs->ev_free);
+  if (fs->ev_free2) hipEventDestroy(fs->ev_free2);
   if (fs->ev_edt) hipEventDestroy(fs->ev_edt);
   if (fs->ev_h2d) hipEventDestroy(fs->ev_h2d);
   delete fs;
@@ -572,6 +580,10 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   struct Guard { revo_ctx* c; ~Guard() { if (c) ctx_free(c); } } guard{c};  // a HIP failure below frees what exists so far
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHECK(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
+  if (env_int("REVO_VOTE_STREAM", 1, 0, 1)) {
+    HIPCHECK(hipStreamCreateWithFlags(&c->vote_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_vote, hipEventDisableTiming));
+  }
   HIPCHECK(hipHostMalloc((void**)&c->h_desc, sizeof(PairDesc)));
   HIPCHECK(hipHostMalloc((void**)&c->h_res, sizeof(revo_pair_result) * 3));
   HIPCHECK(hipHostMalloc((void**)&c->h_seq, sizeof(unsigned) * 4));
@@ -604,6 +616,8 @@ static void ctx_free(revo_ctx* c) {
   hipSetDevice(c->device);
   if (c->build_stream) hipStreamSynchronize(c->build_stream);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->vote_stream) { (void)hipStreamSynchronize(c->vote_stream); (void)hipStreamDestroy(c->vote_stream); }
+  if (c->ev_vote) (void)hipEventDestroy(c->ev_vote);
   for (int k = 0; k < 2; ++k) if (c->pair_streams[k]) (void)hipStreamDestroy(c->pair_streams[k]);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->copy_stream2) (void)hipStreamDestroy(c->copy_stream2);
@@ -721,13 +735,23 @@ static int wait_edt_before_rebuild(FrameSet* fs, hipStream_t s) {
   if (fs->has_edt && fs->edt_stream != s) HIPCHECK(hipStreamWaitEvent(s, fs->ev_edt, 0));
   return REVO_OK;
 }
-static int wait_ready(revo_ctx* c, const revo_pyr* p) {
+static int wait_ready_on(revo_ctx* c, const revo_pyr* p, hipStream_t s) {
   // single-frame pyramids: built on the build stream; batch views: built on the batch's / the caller's stream
   // (revo_batch_build records the event) -- either way the consumer stream is ordered behind the build
-  if (p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_ready, 0));
-  if (p->fs->has_aux) HIPCHECK(hipStreamWaitEvent(c->stream, p->fs->ev_aux, 0));
+  if (p->fs->has_ready) HIPCHECK(hipStreamWaitEvent(s, p->fs->ev_ready, 0));
+  if (p->fs->has_aux) HIPCHECK(hipStreamWaitEvent(s, p->fs->ev_aux, 0));
   // an accessor / single-pair call on a batch view: runs the deferred EDT if it is still pending, waits for it otherwise
-  return run_pending_edt(c, p->fs, c->stream);
+  return run_pending_edt(c, p->fs, s);
+}
+static int wait_ready(revo_ctx* c, const revo_pyr* p) { return wait_ready_on(c, p, c->stream); }
+// The vote stream's work on a pyramid `p` is enqueued.  A single-frame pyramid's planes are recycled behind ev_free2
+// (revo_pyramid_destroy); a batch view's planes belong to the caller, whose ordering promises are all about the tracker
+// stream -- so that stream waits here (batch views are not what the sequential loop runs on).
+static int vote_enqueued(revo_ctx* c, const revo_pyr* p) {
+  if (!c->vote_stream || p->owns_fs) return REVO_OK;
+  HIPCHECK(hipEventRecord(c->ev_vote, c->vote_stream));
+  HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_vote, 0));
+  return REVO_OK;
 }
 
 static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_stride, const void* depth,
@@ -775,6 +799,7 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
     hipStream_t cs = c->frame_copy_stream;
     if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_ready, 0));  // the previous build out of this set's input planes is done
     if (fs->has_free) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_free, 0));    // ... and its last consumer (depth level 0 is read in place)
+    if (fs->has_free2) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_free2, 0));
     if (bgr_stride == brow) HIPCHECK(hipMemcpyAsync(fs->d_bgr, bgr, brow * h, hipMemcpyHostToDevice, cs));
     else HIPCHECK(hipMemcpy2DAsync(fs->d_bgr, brow, bgr, bgr_stride, brow, h, hipMemcpyHostToDevice, cs));
     if (depth_stride == drow) HIPCHECK(hipMemcpyAsync(fs->d_depth, depth, drow * h, hipMemcpyHostToDevice, cs));
@@ -787,6 +812,7 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
     for (int y = 0; y < h; ++y) memcpy(fs->h_bgr + (size_t)y * brow, bgr + (size_t)y * bgr_stride, brow);
     for (int y = 0; y < h; ++y) memcpy((char*)fs->h_depth + (size_t)y * drow, (const char*)depth + (size_t)y * depth_stride, drow);
     if (fs->has_free) HIPCHECK(hipStreamWaitEvent(bs, fs->ev_free, 0));  // last consumer of the recycled set is done
+    if (fs->has_free2) HIPCHECK(hipStreamWaitEvent(bs, fs->ev_free2, 0));
     HIPCHECK(hipMemcpyAsync(fs->d_bgr, fs->h_bgr, brow * h, hipMemcpyHostToDevice, bs));
     HIPCHECK(hipMemcpyAsync(fs->d_depth, fs->h_depth, drow * h, hipMemcpyHostToDevice, bs));
   }
@@ -822,6 +848,7 @@ extern "C" void revo_pyramid_destroy(revo_pyr* p) {
     std::lock_guard<std::mutex> lk(p->ctx->mu);
     hipEventRecord(p->fs->ev_free, p->ctx->stream);
     p->fs->has_free = true;
+    if (p->ctx->vote_stream) { hipEventRecord(p->fs->ev_free2, p->ctx->vote_stream); p->fs->has_free2 = true; }
     p->ctx->pool.push_back(p->fs);
   }
   revo_ctx* c = p->owns_fs ? p->ctx : nullptr;
@@ -1124,7 +1151,8 @@ static int assess_launch(revo_ctx* c, const float T_w_curr[16], const revo_pyr* 
   if (c->past.empty() || !c->ts.check_tracking_results) return REVO_OK;
   const int hl = c->ts.histogram_level;
   if (hl < 0 || hl >= c->geom.n_levels) return fail(REVO_ERR_LEVEL, "histogram_level outside the pyramid");
-  { int rc = wait_ready(c, curr); if (rc) return rc; }
+  hipStream_t vs = c->vote_stream ? c->vote_stream : c->stream;
+  { int rc = wait_ready_on(c, curr, vs); if (rc) return rc; }
   float inv[16];
   mat4_inverse(T_w_curr, inv);
   int nframes = 0;
@@ -1143,8 +1171,9 @@ static int assess_launch(revo_ctx* c, const float T_w_curr[16], const revo_pyr* 
   const unsigned seq = c->seq_next++;
   if (c->seq_next == 0) c->seq_next = 1;
   launch_vote(c->geom, curr->fs->p, curr->frame, hl, nframes, va, c->d_marks, c->d_hist8, c->d_vote_done, c->h_hist8, seq,
-              use_orig, c->stream);
+              use_orig, vs);
   HIPCHECK(hipGetLastError());
+  { int rc = vote_enqueued(c, curr); if (rc) return rc; }
   *nframes_out = nframes;
   *seq_out = seq;
   return REVO_OK;
@@ -1181,6 +1210,8 @@ extern "C" int revo_tracker_assess_quality(revo_ctx* c, const float T_w_curr[16]
   return assess_wait(c, nframes, seq, status, hist4, overlaps4);
 }
 // split form for the VO driver's look-ahead (revo_vo.hip); not part of the public ABI
+// 1: the vote runs beside the tracker stream (revo_vo.hip then launches the look-ahead tracker FIRST)
+extern "C" int revo_vote_overlaps_(const revo_ctx* c) { return c && c->vote_stream ? 1 : 0; }
 extern "C" int revo_assess_launch_(revo_ctx* c, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out) {
   if (!c || !T_w_curr || !curr || curr->ctx != c) return fail(REVO_ERR_INVALID_ARG, "bad argument");
   HIPCHECK(hipSetDevice(c->device));
@@ -1213,14 +1244,16 @@ extern "C" int revo_tracker_add_old_pcl(revo_ctx* c, const revo_pyr* src, int lv
   std::lock_guard<std::mutex> lk(c->mu);
   // the reference copies the Eigen matrix (tracker.cpp:219); the copy stays in HBM, in a
   // recycled buffer sized for the level
-  { int rc = wait_ready(c, src); if (rc) return rc; }
+  hipStream_t vs = c->vote_stream ? c->vote_stream : c->stream;  // the votes that read the copy run there
+  { int rc = wait_ready_on(c, src, vs); if (rc) return rc; }
   Past p{};
   const size_t f = (size_t)src->frame;
   { int rc = past_take(c, (size_t)c->geom.lv[lvl].npix, &p); if (rc) return rc; }
   // the count stays on the device: one kernel copies the n valid points and n (stream ordered)
   launch_copy_cloud(p.d_pts, src->fs->p.pts_trk[lvl] + f * c->geom.lv[lvl].npix, p.d_n, src->fs->p.npts + f * REVO_L + lvl,
-                    c->stream);
+                    vs);
   HIPCHECK(hipGetLastError());
+  { int rc = vote_enqueued(c, src); if (rc) return rc; }
   p.n = -1;
   memcpy(p.T_w, T_w, sizeof(float) * 16);
   p.ts = ts;
@@ -1239,9 +1272,10 @@ extern "C" int revo_tracker_add_old_pcl_host(revo_ctx* c, const float* pcl, size
   { int rc = past_take(c, n, &p); if (rc) return rc; }
   const int ni = (int)n;
   // pageable source: the runtime has read it when the call returns (the caller's matrix may die right after)
-  if (n) HIPCHECK(hipMemcpyAsync(p.d_pts, pcl, sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(p.d_n, &ni, sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream));
+  hipStream_t vs = c->vote_stream ? c->vote_stream : c->stream;
+  if (n) HIPCHECK(hipMemcpyAsync(p.d_pts, pcl, sizeof(float4) * n, hipMemcpyHostToDevice, vs));
+  HIPCHECK(hipMemcpyAsync(p.d_n, &ni, sizeof(int), hipMemcpyHostToDevice, vs));
+  HIPCHECK(hipStreamSynchronize(vs));
   p.n = ni;
   memcpy(p.T_w, T_w, sizeof(float) * 16);
   p.ts = ts;

@@ -18,6 +18,7 @@ extern "C" int revo_track_launch_(revo_ctx*, const revo_pyr* ref, const revo_pyr
 extern "C" int revo_track_wait_(revo_ctx*, int slot, unsigned seq, float R[9], float T[3], float* err, int* status);
 extern "C" int revo_assess_launch_(revo_ctx*, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out);
 extern "C" int revo_assess_wait_(revo_ctx*, int nframes, unsigned seq, int* status);
+extern "C" int revo_vote_overlaps_(const revo_ctx*);
 
 namespace {
 struct M4 {  // column-major 4x4, Eigen::Matrix4f storage
@@ -199,7 +200,11 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
   M4 currPoseInWorld = mul(v->kf.T_w_f, T_KF_N);
   int nvote = -1;
   unsigned vseq = 0;
-  if ((rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
+  // The vote has a stream of its own (revo_host.hip, vote_stream): the look-ahead tracker goes out FIRST, so that it starts one
+  // host hop behind the tracker that just finished instead of behind the vote's two launches as well.  With REVO_VOTE_STREAM=0
+  // both share the tracker stream and the vote must stay in front (its answer is waited for below).
+  const bool spec_first = revo_vote_overlaps_(v->ctx) != 0;
+  if (!spec_first && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
   // what the loop body does when the vote says OK (system.cpp:243-271), computed now so that the next frame's
   // tracker can start behind the vote kernels instead of behind a host round trip
   const Pose ok_last{T_KF_N, v->kf.T_w_f};
@@ -221,6 +226,7 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
       }
     }
   }
+  if (spec_first && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
   if ((rc = revo_assess_wait_(v->ctx, nvote, vseq, &status))) return rc;
   if (status == REVO_TRACKER_STATE_NEW_KF && !v->just_added_kf) {  // system.cpp:203-241
     v->spec_valid = false;  // the look-ahead tracked against the old keyframe: ignored
