@@ -455,10 +455,12 @@ def main():
         def pin(x):
             return torch.from_numpy(np.ascontiguousarray(x)).pin_memory().numpy()
         stream_frames = [(pin(f[0]), pin(f[1]), f[2]) for f in seq]
-        # warm-up: two full-length runs (pools, first touch of every slot, code paths).  One run in about six is ~28 % slow at
-        # points that move with the number of warm-up runs but do not disappear (profiles/r04_single_stream_12_runs.txt: twelve
-        # runs after 1 / 2 / 3 warm-up runs) -- not the collector (disabled inside the runs), not a fixed run index; a host-side
-        # event of the box.  All runs are reported, the median is the figure.
+        # warm-up: two full-length runs (pools, first touch of every slot, code paths).  One run in 15-25 is 20-50 % slow: about one
+        # hipMemcpyAsync in 36 000 (the in-place upload of a page-locked frame) does not return for 6-13 ms, the IO thread sits in it,
+        # the four queued pyramids run out and the consumer waits -- found in round 6 with per-pose / per-submit time stamps and
+        # per-section maxima inside the library (profiles/r06_slow_run_probe.txt; REVO_H2D_KERNEL=1 uploads with a copy kernel instead:
+        # no such run in 900, but a 6-14 % lower median).  7 ms in ~18 000 frames is 0.2 % of a long stream; a 15-ms run shows it as
+        # a slow run.  All runs are reported, the median is the figure.
         for _ in range(2):
             vo.REVO(s, cameraPyr=cam).run(stream_frames)
         runs = []

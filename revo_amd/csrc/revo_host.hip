@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <atomic>
 #include <deque>
@@ -112,6 +113,8 @@ struct Knobs {
   int h2d_mode;        // REVO_H2D_STREAMS: 0 = colour and depth planes on two copy streams, 1 = one stream, 2 = swapped
   int direct_h2d;      // REVO_DIRECT_H2D (default 1): revo_pyramid_create reads page-locked caller rows in place (no staging copy)
   int h2d_max_run_mb;  // REVO_H2D_MAX_RUN_MB: host-buffer batches merge adjacent frames into copies of at most this many MB
+  int h2d_kernel;      // REVO_H2D_KERNEL (default 0): 1 = the in-place frame upload is a copy KERNEL reading the page-locked rows, not hipMemcpyAsync (2: on the build stream)
+  int h2d_wait_poll;   // REVO_H2D_WAIT_POLL (default 1): the in-place frame upload is waited for by polling the event, not by hipEventSynchronize
   int stage_edge_depths;  // REVO_STAGE_EDGE_DEPTHS (default 0): pipelined batches stage the edge pixels' depths in the depth pass
 };
 
@@ -571,6 +574,8 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   c->knobs.h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
   c->knobs.direct_h2d = env_int("REVO_DIRECT_H2D", 1, 0, 1);
   c->knobs.stage_edge_depths = env_int("REVO_STAGE_EDGE_DEPTHS", 0, 0, 1);  // built, bit-exact, 80 MB less traffic per step and 2.6 % SLOWER: off (profiles/r06_ab_stage_edge_depths.txt)
+  c->knobs.h2d_kernel = env_int("REVO_H2D_KERNEL", 0, 0, 2);
+  c->knobs.h2d_wait_poll = env_int("REVO_H2D_WAIT_POLL", 1, 0, 1);
   c->knobs.h2d_max_run_mb = env_int("REVO_H2D_MAX_RUN_MB", 64, 1, 4096);  // (profiles/r06_h2d_run_sizes.txt: 2 / 8 / 24 / 64 MB / unbounded)
   if (opt) c->os = *opt; else revo_opt_settings_default(&c->os);
   if (trk) c->ts = *trk; else revo_tracker_settings_default(&c->ts);
@@ -735,6 +740,81 @@ static int wait_edt_before_rebuild(FrameSet* fs, hipStream_t s) {
   if (fs->has_edt && fs->edt_stream != s) HIPCHECK(hipStreamWaitEvent(s, fs->ev_edt, 0));
   return REVO_OK;
 }
+// The in-place upload of a frame (revo_pyramid_create*, rows in page-locked host memory) as a KERNEL (REVO_H2D_KERNEL=1; the default
+// is hipMemcpyAsync): 16 bytes per lane straight out of the caller's rows over PCIe into the set's input plane; same bytes, same
+// stream, same event.  Why it exists: about one hipMemcpyAsync in 36 000 does not RETURN for 6-13 ms (profiles/r06_slow_run_probe.txt,
+// per-section maxima of 54 000 frame submissions: every other HIP call of a submission stayed below 1.3 ms).  The IO thread sits in
+// that call, the queue of four pyramids runs dry, the consumer waits: THE slow run of the sequential stream's 60-frame measurement
+// (one run in 15-25 at 60-80 % of the median in every round since the second; on a long stream it is 7 ms in ~4 s, 0.2 %).  With the
+// kernel there is no such stall -- 0 slow runs in 900, the longest gap between two poses 1.0 ms -- but the median drops from
+// 4.06-4.20 k to 3.55-3.87 k frames/s (the shader's reads over PCIe run next to the tracker and the build; on the build stream or on
+// a high-priority stream it is the same): a latency-critical consumer can switch it on, throughput keeps the DMA engine.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_upload_rows(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t src_stride,
+                                                     size_t row_bytes, int rows) {
+  // row_bytes is a multiple of 4 for every plane type at every width the library accepts only when w % 4 == 0: handled per byte tail
+  const size_t vec = row_bytes / 16, tail0 = vec * 16;
+  for (int y = blockIdx.y; y < rows; y += gridDim.y) {
+    const uint8_t* s = src + (size_t)y * src_stride;
+    uint8_t* d = dst + (size_t)y * row_bytes;
+    const bool aligned = (((uintptr_t)s | (uintptr_t)d) & 15) == 0;
+    if (aligned) {
+      for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < vec; i += (size_t)gridDim.x * blockDim.x)
+        ((v4u*)d)[i] = __builtin_nontemporal_load((const v4u*)s + i);
+      for (size_t i = tail0 + blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+    } else {
+      for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+  }
+}
+static hipError_t upload_rows(void* dst, const void* src, size_t src_stride, size_t row_bytes, int rows, hipStream_t s) {
+  void* dsrc = nullptr;
+  hipError_t e = hipHostGetDevicePointer(&dsrc, const_cast<void*>(src), 0);  // (registered memory: the device's view of it)
+  if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+  if (src_stride == row_bytes) {  // one contiguous block: treat it as a single long row
+    const size_t bytes = row_bytes * rows;
+    static const int max_blocks = env_int("REVO_UPLOAD_BLOCKS", 64, 1, 4096);
+    const int blocks = (int)std::min<size_t>((size_t)max_blocks, (bytes / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_upload_rows, dim3(blocks, 1), dim3(256), 0, s, (uint8_t*)dst, (const uint8_t*)dsrc, bytes, bytes, 1);
+  } else {
+    hipLaunchKernelGGL(k_upload_rows, dim3(2, std::min(rows, 128)), dim3(256), 0, s, (uint8_t*)dst, (const uint8_t*)dsrc, src_stride, row_bytes, rows);
+  }
+  return hipGetLastError();
+}
+// (debug: the longest time each section of a frame submission has taken so far -- profiles/slow_run_probe.py prints them)
+static std::atomic<unsigned long long> g_sec_max_ns[12];
+extern "C" void revo_debug_section_max_(unsigned long long out[12], int reset) {
+  for (int i = 0; i < 12; ++i) { out[i] = g_sec_max_ns[i].load(); if (reset) g_sec_max_ns[i].store(0); }
+}
+extern "C" void revo_debug_section_note_(int i, unsigned long long ns) {
+  if (i < 0 || i >= 12) return;
+  unsigned long long cur = g_sec_max_ns[i].load(std::memory_order_relaxed);
+  while (ns > cur && !g_sec_max_ns[i].compare_exchange_weak(cur, ns)) {}
+}
+struct SecTimer {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(int i) {
+    const auto n = std::chrono::steady_clock::now();
+    revo_debug_section_note_(i, (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count());
+    t = n;
+  }
+};
+// Waits for an event by POLLING it (the in-place frame upload, ~50-100 us): the IO thread gets its answer a few microseconds after the
+// copy has finished instead of after hipEventSynchronize's park-and-wake; the sequential stream runs 1-3 % faster with it
+// (profiles/r06_slow_run_probe.txt, REVO_H2D_WAIT_POLL=0 / 1 alternating on one box: 4.05-4.19 k against 4.09-4.24 k frames/s).
+static int wait_event_polled(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return REVO_OK;
+    if (e != hipErrorNotReady) { (void)hipGetLastError(); return fail(REVO_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e)); }
+    (void)hipGetLastError();
+    for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
+    if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;  // something is wrong: block
+  }
+  HIPCHECK(hipEventSynchronize(ev));
+  return REVO_OK;
+}
 static int wait_ready_on(revo_ctx* c, const revo_pyr* p, hipStream_t s) {
   // single-frame pyramids: built on the build stream; batch views: built on the batch's / the caller's stream
   // (revo_batch_build records the event) -- either way the consumer stream is ordered behind the build
@@ -762,10 +842,12 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   if (bgr_stride < (size_t)w * 3 || depth_stride < (size_t)w * (is_u16 ? 2 : 4))
     return fail(REVO_ERR_INVALID_ARG, "stride smaller than a row");
   FrameSet* fs = nullptr;
+  SecTimer sec;
   {
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->pool.empty()) { fs = c->pool.back(); c->pool.pop_back(); }
   }
+  sec.lap(0);  // the context's lock + the pool
   if (!fs) {
     int rc = frameset_create(c, 1, true, &fs);
     if (rc) return rc;
@@ -790,23 +872,42 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   const bool direct = c->knobs.direct_h2d && page_locked(bgr) && page_locked(depth) &&
                       page_locked(bgr + (size_t)(h - 1) * bgr_stride + brow - 1) &&
                       page_locked((const char*)depth + (size_t)(h - 1) * depth_stride + drow - 1);
+  sec.lap(1);  // pointer attributes (and a new frame set, if the pool was empty)
   if (direct) {
     {
       std::lock_guard<std::mutex> lk(c->mu);
-      if (!c->frame_copy_stream) HIPCHECK(hipStreamCreateWithFlags(&c->frame_copy_stream, hipStreamNonBlocking));
+      if (!c->frame_copy_stream) {
+        // (experiment knob REVO_COPY_STREAM_PRIO: 1 = a high-priority stream, which HIP serves from a hardware-queue pool of its own)
+        int lo = 0, hi = 0;
+        if (env_int("REVO_COPY_STREAM_PRIO", 0, 0, 1) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+          HIPCHECK(hipStreamCreateWithPriority(&c->frame_copy_stream, hipStreamNonBlocking, hi));
+        else
+          HIPCHECK(hipStreamCreateWithFlags(&c->frame_copy_stream, hipStreamNonBlocking));
+      }
     }
     if (!fs->ev_h2d) HIPCHECK(hipEventCreateWithFlags(&fs->ev_h2d, hipEventDisableTiming));
-    hipStream_t cs = c->frame_copy_stream;
+    hipStream_t cs = c->knobs.h2d_kernel == 2 ? bs : c->frame_copy_stream;  // (2: experiment -- the upload kernel in front of the build, same stream)
     if (fs->has_ready) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_ready, 0));  // the previous build out of this set's input planes is done
     if (fs->has_free) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_free, 0));    // ... and its last consumer (depth level 0 is read in place)
     if (fs->has_free2) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_free2, 0));
-    if (bgr_stride == brow) HIPCHECK(hipMemcpyAsync(fs->d_bgr, bgr, brow * h, hipMemcpyHostToDevice, cs));
+    sec.lap(6);  // the copy stream's waits for the set's previous users
+    // (memory the device cannot address through hipHostGetDevicePointer goes the old way)
+    if (c->knobs.h2d_kernel && upload_rows(fs->d_bgr, bgr, bgr_stride, brow, h, cs) == hipSuccess) {}
+    else if (bgr_stride == brow) HIPCHECK(hipMemcpyAsync(fs->d_bgr, bgr, brow * h, hipMemcpyHostToDevice, cs));
     else HIPCHECK(hipMemcpy2DAsync(fs->d_bgr, brow, bgr, bgr_stride, brow, h, hipMemcpyHostToDevice, cs));
-    if (depth_stride == drow) HIPCHECK(hipMemcpyAsync(fs->d_depth, depth, drow * h, hipMemcpyHostToDevice, cs));
+    sec.lap(7);  // upload, colour
+    if (c->knobs.h2d_kernel && upload_rows(fs->d_depth, depth, depth_stride, drow, h, cs) == hipSuccess) {}
+    else if (depth_stride == drow) HIPCHECK(hipMemcpyAsync(fs->d_depth, depth, drow * h, hipMemcpyHostToDevice, cs));
     else HIPCHECK(hipMemcpy2DAsync(fs->d_depth, drow, depth, depth_stride, drow, h, hipMemcpyHostToDevice, cs));
+    sec.lap(8);  // upload, depth
     HIPCHECK(hipEventRecord(fs->ev_h2d, cs));
+    sec.lap(9);  // hipEventRecord
     HIPCHECK(hipStreamWaitEvent(bs, fs->ev_h2d, 0));
-    HIPCHECK(hipEventSynchronize(fs->ev_h2d));  // the clone exists: the caller's buffers are free again
+    sec.lap(2);  // the build stream's wait for the copies
+    // the clone exists: the caller's buffers are free again
+    if (c->knobs.h2d_wait_poll) { int rc = wait_event_polled(fs->ev_h2d); if (rc) return rc; }
+    else HIPCHECK(hipEventSynchronize(fs->ev_h2d));
+    sec.lap(3);  // waiting for them
   } else {
     if (fs->has_ready) HIPCHECK(hipEventSynchronize(fs->ev_ready));  // previous upload out of this staging is done
     for (int y = 0; y < h; ++y) memcpy(fs->h_bgr + (size_t)y * brow, bgr + (size_t)y * bgr_stride, brow);
@@ -821,6 +922,7 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
   enqueue_build(c, fs, fs->d_bgr, is_u16 ? nullptr : fs->d_depth, is_u16 ? (const uint16_t*)fs->d_depth : nullptr, alpha, bs, true);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipEventRecord(fs->ev_ready, bs));
+  sec.lap(4);  // enqueueing the build
   fs->has_ready = true;
   fs->ready_stream = bs;
   revo_pyr* p = new revo_pyr{c, fs, 0, true, false, ts, false, false};
@@ -998,12 +1100,27 @@ static int check_pair(const revo_ctx* c, const revo_pyr* ref, const revo_pyr* cu
 // Waits for a sequence word a kernel writes (system scope) after its results in pinned host memory: a short spin
 // (the kernel is usually about to finish: a stream synchronise costs a sleep / wake-up of the calling thread),
 // then the stream.
+// (debug: how often the spin below ran out and what the longest wait was -- profiles/slow_run_probe.py prints them)
+static std::atomic<unsigned long long> g_wait_fallbacks{0}, g_wait_max_ns{0}, g_wait_calls{0};
+extern "C" void revo_debug_wait_stats_(unsigned long long out[3]) {
+  out[0] = g_wait_calls.load(); out[1] = g_wait_fallbacks.load(); out[2] = g_wait_max_ns.load();
+}
 static int wait_seq(revo_ctx* c, volatile unsigned* word, unsigned want) {
-  for (int spin = 0; spin < 200000; ++spin) {
-    if (*word == want) { std::atomic_thread_fence(std::memory_order_acquire); return REVO_OK; }
+  static const int spin_limit = env_int("REVO_WAIT_SPINS", 200000, 1000, 2000000000);
+  const auto t0 = std::chrono::steady_clock::now();
+  g_wait_calls.fetch_add(1, std::memory_order_relaxed);
+  auto note = [&]() {
+    const unsigned long long ns = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    unsigned long long cur = g_wait_max_ns.load(std::memory_order_relaxed);
+    while (ns > cur && !g_wait_max_ns.compare_exchange_weak(cur, ns)) {}
+  };
+  for (int spin = 0; spin < spin_limit; ++spin) {
+    if (*word == want) { std::atomic_thread_fence(std::memory_order_acquire); note(); return REVO_OK; }
     __builtin_ia32_pause();
   }
+  g_wait_fallbacks.fetch_add(1, std::memory_order_relaxed);
   HIPCHECK(hipStreamSynchronize(c->stream));
+  note();
   if (*word != want) return fail(REVO_ERR_HIP, "a kernel finished without publishing its result");
   return REVO_OK;
 }

@@ -1,5 +1,6 @@
 // revo_vo.hip -- REVO::start sequencing (system/system.cpp:84-305) on top of the C ABI.
 // Host-only code: the device work is what revo_pyramid_* / revo_tracker_* enqueue.
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <condition_variable>
@@ -19,6 +20,7 @@ extern "C" int revo_track_wait_(revo_ctx*, int slot, unsigned seq, float R[9], f
 extern "C" int revo_assess_launch_(revo_ctx*, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out);
 extern "C" int revo_assess_wait_(revo_ctx*, int nframes, unsigned seq, int* status);
 extern "C" int revo_vote_overlaps_(const revo_ctx*);
+extern "C" void revo_debug_section_note_(int i, unsigned long long ns);
 
 namespace {
 struct M4 {  // column-major 4x4, Eigen::Matrix4f storage
@@ -133,9 +135,11 @@ extern "C" int revo_vo_submit(revo_vo* v, const uint8_t* bgr, size_t bgr_stride,
   const int rc = revo_pyramid_create(v->ctx, bgr, bgr_stride, depth, depth_stride, ts, &f.pyr);
   if (rc) return rc;
   {
+    const auto tq = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(v->qmu);
     v->qcv.wait(lk, [&] { return v->max_queue <= 0 || (int)v->queue.size() < v->max_queue; });
     v->queue.push_back(f);
+    revo_debug_section_note_(5, (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tq).count());
   }
   v->qcv.notify_all();
   return REVO_OK;

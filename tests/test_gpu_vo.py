@@ -238,3 +238,40 @@ def test_page_locked_frames_are_read_in_place_and_give_the_same_bits(monkeypatch
     off = vo.REVO(s).run(refilled(), io_thread=False)  # (a new context: the knob is read per context)
     for (Ma, ka), (Mb, kb) in zip(off, want):
         assert ka == kb and np.array_equal(Ma, Mb)
+
+
+def test_in_place_upload_of_padded_rows_kernel_and_memcpy_paths(monkeypatch):
+    """The in-place upload out of page-locked rows is a copy kernel (REVO_H2D_KERNEL, default 1; 0 = hipMemcpyAsync / hipMemcpy2DAsync):
+    compact rows, padded rows (row stride > row bytes, the kernel's per-row form), odd padding (unaligned rows: the byte path) --
+    every variant must give the pyramid of the plain pageable frame, bit for bit."""
+    import ctypes as C
+    import torch
+    from revo_amd import _lib, api, synth
+    from revo_amd.settings import ImgPyramidSettings
+    s = ImgPyramidSettings.scaled(320, 240, 3, hist_patch=(10, 5, 0, 0, 0, 0))
+    bgr, dep = synth.make_sequence(5, s, 1, max_t=0.01, max_rot_deg=0.4)[0][:2]
+    h, w = s.height, s.width
+    L = _lib.lib()
+
+    def planes(pyr):
+        return [pyr.returnEdges(l).copy() for l in range(3)] + [pyr.return3DEdges(l).copy() for l in range(3)]
+
+    for knob in ("1", "0"):
+        monkeypatch.setenv("REVO_H2D_KERNEL", knob)
+        cam = api.CameraPyr(s)  # (the knob is read per context)
+        want = planes(api.ImgPyramidRGBD(s, cam, bgr, dep, 0.0))
+        for pad_b, pad_d in ((0, 0), (64, 64), (7, 12)):
+            sb, sd = w * 3 + pad_b, w * 4 + pad_d
+            hb = torch.zeros((h, sb), dtype=torch.uint8).pin_memory()
+            hd = torch.zeros((h, sd), dtype=torch.uint8).pin_memory()
+            hb.numpy()[:, :w * 3] = bgr.reshape(h, w * 3)
+            hd.numpy()[:, :w * 4] = np.ascontiguousarray(dep, np.float32).view(np.uint8).reshape(h, w * 4)
+            hnd = C.c_void_p()
+            rc = L.revo_pyramid_create(cam._h, C.cast(hb.data_ptr(), _lib.u8p), sb, C.cast(hd.data_ptr(), _lib.f32p), sd, 0.0,
+                                       C.byref(hnd))
+            assert rc == 0, (knob, pad_b, pad_d)
+            hb.zero_()  # the call returned: the clone exists
+            hd.zero_()
+            got = planes(api.ImgPyramidRGBD(s, cam, _handle=hnd))
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (knob, pad_b, pad_d)
