@@ -1335,9 +1335,22 @@ extern "C" int revo_assess_launch_(revo_ctx* c, const float T_w_curr[16], const 
   std::lock_guard<std::mutex> lk(c->mu);
   return assess_launch(c, T_w_curr, curr, nframes_out, seq_out);
 }
-extern "C" int revo_assess_wait_(revo_ctx* c, int nframes, unsigned seq, int* status) {
+// ratio_out (may be null): overlapMeasure / overlaps[0] of this vote -- how far the frame is from asking for a new keyframe (< 1 does,
+// tracker.cpp:184); +inf while fewer than three past clouds vote (the answer is OK whatever the numbers) or nothing voted
+extern "C" int revo_assess_wait_(revo_ctx* c, int nframes, unsigned seq, int* status, float* ratio_out) {
   if (!c) return fail(REVO_ERR_INVALID_ARG, "null context");
-  return assess_wait(c, nframes, seq, status, nullptr, nullptr);
+  int32_t ov[4] = {0, 0, 0, 0};
+  const int rc = assess_wait(c, nframes, seq, status, nullptr, ov);
+  if (ratio_out) {
+    *ratio_out = INFINITY;
+    if (rc == REVO_OK && nframes >= 3 && ov[0] > 0) {
+      const float wts[4] = {0.f, 1.f, 1.25f, 1.5f};
+      float m = 0.0f;
+      for (int k = 1; k < 1 + nframes && k < 4; ++k) m += ov[k] * wts[k];
+      *ratio_out = m / (float)ov[0];
+    }
+  }
+  return rc;
 }
 
 // a past-cloud buffer for at least `need` points: recycled if one is large enough (no hipMalloc per frame in

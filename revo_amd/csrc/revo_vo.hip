@@ -1,6 +1,8 @@
 // revo_vo.hip -- REVO::start sequencing (system/system.cpp:84-305) on top of the C ABI.
 // Host-only code: the device work is what revo_pyramid_* / revo_tracker_* enqueue.
 #include <chrono>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <condition_variable>
@@ -18,7 +20,7 @@ extern "C" int revo_track_launch_(revo_ctx*, const revo_pyr* ref, const revo_pyr
                                   unsigned* seq_out);
 extern "C" int revo_track_wait_(revo_ctx*, int slot, unsigned seq, float R[9], float T[3], float* err, int* status);
 extern "C" int revo_assess_launch_(revo_ctx*, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out);
-extern "C" int revo_assess_wait_(revo_ctx*, int nframes, unsigned seq, int* status);
+extern "C" int revo_assess_wait_(revo_ctx*, int nframes, unsigned seq, int* status, float* ratio_out);
 extern "C" int revo_vote_overlaps_(const revo_ctx*);
 extern "C" void revo_debug_section_note_(int i, unsigned long long ns);
 
@@ -65,6 +67,12 @@ struct revo_vo {
   int spec_slot = 0;
   unsigned spec_seq = 0;
   int slot = 0;  // result slot of the next non-speculative launch
+  // ... unless the PREVIOUS vote was close to asking for a new keyframe (overlap ratio below kf_guard; the ratio decays smoothly
+  // from ~2.5 behind a keyframe to 1, where the change happens): then the look-ahead is held back until this frame's vote is in --
+  // ~35 us later when the keyframe stays, and no tracker against the old keyframe (190 us on the stream the re-track needs) when
+  // it changes.  Launch timing only: every launch that counts has the same arguments either way.  REVO_KF_GUARD=0 switches it off.
+  float last_ratio = INFINITY;
+  float kf_guard = 1.08f;
 };
 
 extern "C" int revo_vo_create(revo_ctx* ctx, revo_vo** out) {
@@ -73,6 +81,7 @@ extern "C" int revo_vo_create(revo_ctx* ctx, revo_vo** out) {
   v->ctx = ctx;
   revo_ctx_retain_(ctx);
   v->hist_level = revo_ctx_histogram_level(ctx);
+  { const char* e = getenv("REVO_KF_GUARD"); if (e && *e) v->kf_guard = (float)atof(e); }
   // REVO::start makes a fresh TrackerNew (system.cpp:107): a driver never votes against the clouds
   // another driver on the same context left behind
   revo_tracker_reset_past_(ctx);
@@ -208,7 +217,10 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
   // host hop behind the tracker that just finished instead of behind the vote's two launches as well.  With REVO_VOTE_STREAM=0
   // both share the tracker stream and the vote must stay in front (its answer is waited for below).
   const bool spec_first = revo_vote_overlaps_(v->ctx) != 0;
-  if (!spec_first && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
+  // (the previous vote was close to a keyframe change and this frame's vote counts -- the one right behind a new keyframe is
+  // ignored, system.cpp:203: hold the look-ahead until the vote is in)
+  const bool hold = spec_first && !v->just_added_kf && v->last_ratio < v->kf_guard;
+  if ((!spec_first || hold) && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
   // what the loop body does when the vote says OK (system.cpp:243-271), computed now so that the next frame's
   // tracker can start behind the vote kernels instead of behind a host round trip
   const Pose ok_last{T_KF_N, v->kf.T_w_f};
@@ -216,7 +228,7 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
   const M4 ok_T_NM1_N = mul(inverse(v->last.world()), ok_w1);
   float ok_R[9], ok_T[3];
   to_RT(mul(ok_last.T_kf_curr, ok_T_NM1_N), ok_R, ok_T);
-  {
+  auto look_ahead = [&]() {
     revo_pyr* nxt = nullptr;
     {
       std::lock_guard<std::mutex> lk(v->qmu);
@@ -229,10 +241,15 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
         v->spec_valid = true; v->spec_pyr = nxt; v->spec_slot = sslot; v->spec_seq = sseq;
       }
     }
-  }
-  if (spec_first && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
-  if ((rc = revo_assess_wait_(v->ctx, nvote, vseq, &status))) return rc;
-  if (status == REVO_TRACKER_STATE_NEW_KF && !v->just_added_kf) {  // system.cpp:203-241
+  };
+  if (!hold) look_ahead();
+  if (spec_first && !hold && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
+  float ratio = INFINITY;
+  if ((rc = revo_assess_wait_(v->ctx, nvote, vseq, &status, &ratio))) return rc;
+  v->last_ratio = ratio;
+  const bool change_kf = status == REVO_TRACKER_STATE_NEW_KF && !v->just_added_kf;
+  if (hold && !change_kf) look_ahead();  // the keyframe stays: the held-back tracker goes out now
+  if (change_kf) {  // system.cpp:203-241
     v->spec_valid = false;  // the look-ahead tracked against the old keyframe: ignored
     revo_pyr* old_kf = v->kf.pyr;
     v->kf = v->prev;
