@@ -170,6 +170,7 @@ struct revo_pyr {
   double ts;
   bool table_built;
   bool ref_list_built;  // edges3DPyr in the reference's order (the hot path only writes the tile-ordered list)
+  bool dt_ready = false;  // the distance transforms are already enqueued on the tracker stream (revo_pyramid_prepare_keyframe_)
 };
 
 struct revo_batch {
@@ -962,10 +963,24 @@ extern "C" int revo_pyramid_make_keyframe(revo_pyr* p) {
   if (!p) return fail(REVO_ERR_INVALID_ARG, "null pyramid");
   HIPCHECK(hipSetDevice(p->ctx->device));
   { int rc = wait_ready(p->ctx, p); if (rc) return rc; }
-  launch_keyframe(p->ctx->geom, p->fs->p, p->frame, 1, 1, p->ctx->stream);
+  if (!p->dt_ready) launch_keyframe(p->ctx->geom, p->fs->p, p->frame, 1, 1, p->ctx->stream);
   HIPCHECK(hipGetLastError());
+  p->dt_ready = false;  // (a second makeKeyframe computes again, like the reference)
   p->is_kf = true;
   p->table_built = false;
+  return REVO_OK;
+}
+// The distance transforms of a frame that is LIKELY to become the keyframe (revo_vo.hip: the previous vote was close to a change),
+// enqueued while the vote that decides it is still running; revo_pyramid_make_keyframe then finds them in place.  The frame is
+// not a keyframe until that call; if it never comes the planes are simply never read (single-frame pyramids only).
+extern "C" int revo_pyramid_prepare_keyframe_(revo_pyr* p) {
+  if (!p) return fail(REVO_ERR_INVALID_ARG, "null pyramid");
+  if (!p->owns_fs || p->is_kf || p->dt_ready) return REVO_OK;
+  HIPCHECK(hipSetDevice(p->ctx->device));
+  { int rc = wait_ready(p->ctx, p); if (rc) return rc; }
+  launch_keyframe(p->ctx->geom, p->fs->p, p->frame, 1, 1, p->ctx->stream);
+  HIPCHECK(hipGetLastError());
+  p->dt_ready = true;
   return REVO_OK;
 }
 extern "C" int revo_pyramid_is_keyframe(const revo_pyr* p) { return p && p->is_kf; }

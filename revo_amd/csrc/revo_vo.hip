@@ -22,6 +22,7 @@ extern "C" int revo_track_wait_(revo_ctx*, int slot, unsigned seq, float R[9], f
 extern "C" int revo_assess_launch_(revo_ctx*, const float T_w_curr[16], const revo_pyr* curr, int* nframes_out, unsigned* seq_out);
 extern "C" int revo_assess_wait_(revo_ctx*, int nframes, unsigned seq, int* status, float* ratio_out);
 extern "C" int revo_vote_overlaps_(const revo_ctx*);
+extern "C" int revo_pyramid_prepare_keyframe_(revo_pyr*);
 extern "C" void revo_debug_section_note_(int i, unsigned long long ns);
 
 namespace {
@@ -243,6 +244,9 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
     }
   };
   if (!hold) look_ahead();
+  // held back: the tracker stream is idle while the vote runs -- the distance transforms of the frame that would become the keyframe
+  // (the previous one, system.cpp:205-215) go there now; makeKeyframe below finds them done
+  else if (v->prev.pyr && v->prev.pyr != v->kf.pyr) (void)revo_pyramid_prepare_keyframe_(v->prev.pyr);
   if (spec_first && !hold && (rc = revo_assess_launch_(v->ctx, currPoseInWorld.m, curr.pyr, &nvote, &vseq))) return rc;
   float ratio = INFINITY;
   if ((rc = revo_assess_wait_(v->ctx, nvote, vseq, &status, &ratio))) return rc;
@@ -262,6 +266,13 @@ extern "C" int revo_vo_track_next(revo_vo* v, float pose_out[16], int* new_kf_ou
     if ((rc = revo_tracker_track_frames(v->ctx, v->kf.pyr, curr.pyr, v->R, v->T, &err, &status, nullptr, nullptr))) return rc;
     T_KF_N = from_RT(v->R, v->T);
     currPoseInWorld = mul(v->kf.T_w_f, T_KF_N);
+    if (spec_first) {
+      // the next frame's tracker goes out before the second vote (nobody acts on its answer: just_added_kf) -- its initialisation
+      // is what the end of this body computes from the same matrices in the same order (system.cpp:267-271)
+      const Pose nl{T_KF_N, v->kf.T_w_f};
+      to_RT(mul(nl.T_kf_curr, mul(inverse(v->last.world()), nl.world())), ok_R, ok_T);
+      look_ahead();
+    }
     if ((rc = revo_tracker_assess_quality(v->ctx, currPoseInWorld.m, curr.pyr, &status, nullptr, nullptr))) return rc;
     v->just_added_kf = true;
     new_kf = 1;
