@@ -455,8 +455,9 @@ def main():
         def pin(x):
             return torch.from_numpy(np.ascontiguousarray(x)).pin_memory().numpy()
         stream_frames = [(pin(f[0]), pin(f[1]), f[2]) for f in seq]
-        # warm-up: two full-length runs (pools, first touch of every slot, code paths).  One run in 15-25 is 20-50 % slow: about one
-        # hipMemcpyAsync in 36 000 (the in-place upload of a page-locked frame) does not return for 6-13 ms, the IO thread sits in it,
+        # warm-up: two full-length runs (pools, first touch of every slot, code paths).  One run in 15-25 is 20-50 % slow: once in some ten
+        # thousand frames a HIP call of the IO thread (hipMemcpyAsync, the in-place upload of a page-locked frame, in five observed cases
+        # out of six; a build's kernel launches once) does not return for 6-13 ms, the IO thread sits in it,
         # the four queued pyramids run out and the consumer waits -- found in round 6 with per-pose / per-submit time stamps and
         # per-section maxima inside the library (profiles/r06_slow_run_probe.txt; REVO_H2D_KERNEL=1 uploads with a copy kernel instead:
         # no such run in 900, but a 6-14 % lower median).  7 ms in ~18 000 frames is 0.2 % of a long stream; a 15-ms run shows it as
@@ -465,6 +466,10 @@ def main():
             vo.REVO(s, cameraPyr=cam).run(stream_frames)
         runs = []
         import gc
+        import ctypes
+        from revo_amd import _lib as _revo_lib
+        sec = (ctypes.c_ulonglong * 12)()
+        _revo_lib.lib().revo_debug_section_max_(sec, 1)  # (reset: the maxima below belong to the timed runs)
         for _ in range(max(1, a.single_stream_runs)):  # all runs reported, the MEDIAN is the figure
             drv = vo.REVO(s, cameraPyr=cam)
             # (r03 / r04: the SECOND of the five runs was reproducibly ~30 % slow in every invocation -- a deterministic point in
@@ -478,7 +483,13 @@ def main():
             finally:
                 gc.enable()
         rpe = synth.rpe_rmse([p[1] for p in drv.poses], [f[3] for f in seq])
-        seq_gpu = {"runs": runs, "keyframes": drv.nKeyFrames, "rpe": rpe, "poses": [np.array(p[1]) for p in drv.poses],
+        # the longest any section of a frame submission took inside the timed runs (the library keeps the maxima): a slow run shows
+        # up here as ONE hipMemcpyAsync of several milliseconds (profiles/r06_slow_run_probe.txt)
+        _revo_lib.lib().revo_debug_section_max_(sec, 0)
+        sec_names = ["lock_and_pool", "pointer_attributes", "build_stream_waits_for_copies", "wait_for_copies", "enqueue_build",
+                     "wait_for_queue_room", "copy_stream_waits", "hipMemcpyAsync_colour", "hipMemcpyAsync_depth", "hipEventRecord"]
+        io_max_ms = {nm: sec[i] / 1e6 for i, nm in enumerate(sec_names)}
+        seq_gpu = {"runs": runs, "io_max_ms": io_max_ms, "keyframes": drv.nKeyFrames, "rpe": rpe, "poses": [np.array(p[1]) for p in drv.poses],
                    "gt": [f[3] for f in seq],
                    "ate": synth.ate_rmse([p[1] for p in drv.poses], [f[3] for f in seq])}
         del drv
@@ -1033,6 +1044,7 @@ def main():
             cpu_seq_2core = nseq / float(np.median(times_seq[1:]))
         out["single_stream"] = {"frames_per_s": n / dt_seq, "statistic": "median of %d runs" % len(runs),
                                 "frames_per_s_runs": [n / t for t in runs], "frames": n,
+                                "io_thread_longest_section_ms": seq_gpu["io_max_ms"],
                                 "keyframes": seq_gpu["keyframes"],
                                 "ate_rmse_vs_ground_truth_m": ate_seq,
                                 # the oracle ran the same frames (its first `oracle_frames`): trajectory against trajectory, and

@@ -744,7 +744,8 @@ static int wait_edt_before_rebuild(FrameSet* fs, hipStream_t s) {
 // The in-place upload of a frame (revo_pyramid_create*, rows in page-locked host memory) as a KERNEL (REVO_H2D_KERNEL=1; the default
 // is hipMemcpyAsync): 16 bytes per lane straight out of the caller's rows over PCIe into the set's input plane; same bytes, same
 // stream, same event.  Why it exists: about one hipMemcpyAsync in 36 000 does not RETURN for 6-13 ms (profiles/r06_slow_run_probe.txt,
-// per-section maxima of 54 000 frame submissions: every other HIP call of a submission stayed below 1.3 ms).  The IO thread sits in
+// per-section maxima of 54 000 frame submissions: every other HIP call of a submission stayed below 1.3 ms; inside bench.py a
+// build's kernel launches were seen to take 9 ms once as well).  The IO thread sits in
 // that call, the queue of four pyramids runs dry, the consumer waits: THE slow run of the sequential stream's 60-frame measurement
 // (one run in 15-25 at 60-80 % of the median in every round since the second; on a long stream it is 7 ms in ~4 s, 0.2 %).  With the
 // kernel there is no such stall -- 0 slow runs in 900, the longest gap between two poses 1.0 ms -- but the median drops from
@@ -1148,6 +1149,19 @@ static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, 
   { int rc = wait_ready(c, ref); if (rc) return rc; rc = wait_ready(c, curr); if (rc) return rc; }
   TrackParams tp1 = tp;
   tp1.redundant_n = c->knobs.redundant_one;
+  // a single pair has the chip to itself: one more retry next to the candidate at the two finest levels costs its 16 workgroups
+  // little and saves passes (sequential stream 4.23 -> 4.29 k frames/s, profiles/r06_single_stream_sweep.txt).  REVO_TRACK_KSPEC_ONE:
+  // one digit per level (finest first) or one for all; an explicit REVO_TRACK_KSPEC applies to single pairs too.
+  {
+    static const std::string e1 = [] { const char* e = getenv("REVO_TRACK_KSPEC_ONE"); return std::string(e ? e : ""); }();
+    static const bool batch_set = [] { const char* e = getenv("REVO_TRACK_KSPEC"); return e && *e; }();
+    if (!e1.empty() || !batch_set)
+      for (int i = 0; i < REVO_L; ++i) {
+        int k = i < 2 ? 3 : TRACK_KMAX;
+        if (e1.size() == 1) k = e1[0] - '0'; else if (e1.size() > 1) k = e1[std::min<size_t>(i, e1.size() - 1)] - '0';
+        tp1.kspec[i] = std::max(1, std::min(TRACK_KMAX, k));
+      }
+  }
   const unsigned seq = c->seq_next++;
   if (c->seq_next == 0) c->seq_next = 1;
   const int rc = chained_track_launch(c->device, c->knobs.track_depth, c->stream, [&](unsigned* d_resident) {
