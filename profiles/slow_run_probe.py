@@ -92,6 +92,10 @@ def main():
         import torch
         frames = [(torch.from_numpy(np.ascontiguousarray(f[0])).pin_memory().numpy(),
                    torch.from_numpy(np.ascontiguousarray(f[1])).pin_memory().numpy(), f[2]) for f in frames]
+    if os.environ.get("PROBE_SCHEDULE"):  # hipSetDeviceFlags: 1 = hipDeviceScheduleSpin, 2 = Yield, 4 = BlockingSync
+        import ctypes as C0
+        hip = C0.CDLL("libamdhip64.so")
+        print("hipSetDeviceFlags(%s) -> %d" % (os.environ["PROBE_SCHEDULE"], hip.hipSetDeviceFlags(int(os.environ["PROBE_SCHEDULE"]))))
     cam = api.CameraPyr(s)
     for _ in range(2):
         vo.REVO(s, cameraPyr=cam).run(frames)
