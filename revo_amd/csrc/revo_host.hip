@@ -113,6 +113,9 @@ struct Knobs {
   int h2d_mode;        // REVO_H2D_STREAMS: 0 = colour and depth planes on two copy streams, 1 = one stream, 2 = swapped
   int direct_h2d;      // REVO_DIRECT_H2D (default 1): revo_pyramid_create reads page-locked caller rows in place (no staging copy)
   int h2d_max_run_mb;  // REVO_H2D_MAX_RUN_MB: host-buffer batches merge adjacent frames into copies of at most this many MB
+  bool kspec_one_set;  // REVO_TRACK_KSPEC_ONE (or no REVO_TRACK_KSPEC at all): the single-pair launches' own speculation depths
+  int kspec_one[REVO_L];
+  int upload_blocks;   // REVO_UPLOAD_BLOCKS: workgroups of the upload kernel for one contiguous plane
   int h2d_kernel;      // REVO_H2D_KERNEL (default 0): 1 = the in-place frame upload is a copy KERNEL reading the page-locked rows, not hipMemcpyAsync (2: on the build stream)
   int h2d_wait_poll;   // REVO_H2D_WAIT_POLL (default 1): the in-place frame upload is waited for by polling the event, not by hipEventSynchronize
   int stage_edge_depths;  // REVO_STAGE_EDGE_DEPTHS (default 0): pipelined batches stage the edge pixels' depths in the depth pass
@@ -575,6 +578,18 @@ extern "C" int revo_ctx_create(int device, const revo_pyr_settings* pyr, const r
   c->knobs.h2d_mode = env_int("REVO_H2D_STREAMS", 0, 0, 2);
   c->knobs.direct_h2d = env_int("REVO_DIRECT_H2D", 1, 0, 1);
   c->knobs.stage_edge_depths = env_int("REVO_STAGE_EDGE_DEPTHS", 0, 0, 1);  // built, bit-exact, 80 MB less traffic per step and 2.6 % SLOWER: off (profiles/r06_ab_stage_edge_depths.txt)
+  {
+    const char* e1 = getenv("REVO_TRACK_KSPEC_ONE");
+    const char* eb = getenv("REVO_TRACK_KSPEC");
+    const size_t n1 = e1 ? strlen(e1) : 0;
+    c->knobs.kspec_one_set = n1 > 0 || !(eb && *eb);
+    for (int i = 0; i < REVO_L; ++i) {
+      int k = i < 2 ? 3 : TRACK_KMAX;
+      if (n1 == 1) k = e1[0] - '0'; else if (n1 > 1) k = e1[std::min<size_t>(i, n1 - 1)] - '0';
+      c->knobs.kspec_one[i] = std::max(1, std::min(TRACK_KMAX, k));
+    }
+  }
+  c->knobs.upload_blocks = env_int("REVO_UPLOAD_BLOCKS", 64, 1, 4096);
   c->knobs.h2d_kernel = env_int("REVO_H2D_KERNEL", 0, 0, 2);
   c->knobs.h2d_wait_poll = env_int("REVO_H2D_WAIT_POLL", 1, 0, 1);
   c->knobs.h2d_max_run_mb = env_int("REVO_H2D_MAX_RUN_MB", 64, 1, 4096);  // (profiles/r06_h2d_run_sizes.txt: 2 / 8 / 24 / 64 MB / unbounded)
@@ -769,13 +784,12 @@ __global__ void __launch_bounds__(256) k_upload_rows(uint8_t* __restrict__ dst, 
     }
   }
 }
-static hipError_t upload_rows(void* dst, const void* src, size_t src_stride, size_t row_bytes, int rows, hipStream_t s) {
+static hipError_t upload_rows(void* dst, const void* src, size_t src_stride, size_t row_bytes, int rows, int max_blocks, hipStream_t s) {
   void* dsrc = nullptr;
   hipError_t e = hipHostGetDevicePointer(&dsrc, const_cast<void*>(src), 0);  // (registered memory: the device's view of it)
   if (e != hipSuccess) { (void)hipGetLastError(); return e; }
   if (src_stride == row_bytes) {  // one contiguous block: treat it as a single long row
     const size_t bytes = row_bytes * rows;
-    static const int max_blocks = env_int("REVO_UPLOAD_BLOCKS", 64, 1, 4096);
     const int blocks = (int)std::min<size_t>((size_t)max_blocks, (bytes / 16 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_upload_rows, dim3(blocks, 1), dim3(256), 0, s, (uint8_t*)dst, (const uint8_t*)dsrc, bytes, bytes, 1);
   } else {
@@ -894,11 +908,11 @@ static int pyramid_create_common(revo_ctx* c, const uint8_t* bgr, size_t bgr_str
     if (fs->has_free2) HIPCHECK(hipStreamWaitEvent(cs, fs->ev_free2, 0));
     sec.lap(6);  // the copy stream's waits for the set's previous users
     // (memory the device cannot address through hipHostGetDevicePointer goes the old way)
-    if (c->knobs.h2d_kernel && upload_rows(fs->d_bgr, bgr, bgr_stride, brow, h, cs) == hipSuccess) {}
+    if (c->knobs.h2d_kernel && upload_rows(fs->d_bgr, bgr, bgr_stride, brow, h, c->knobs.upload_blocks, cs) == hipSuccess) {}
     else if (bgr_stride == brow) HIPCHECK(hipMemcpyAsync(fs->d_bgr, bgr, brow * h, hipMemcpyHostToDevice, cs));
     else HIPCHECK(hipMemcpy2DAsync(fs->d_bgr, brow, bgr, bgr_stride, brow, h, hipMemcpyHostToDevice, cs));
     sec.lap(7);  // upload, colour
-    if (c->knobs.h2d_kernel && upload_rows(fs->d_depth, depth, depth_stride, drow, h, cs) == hipSuccess) {}
+    if (c->knobs.h2d_kernel && upload_rows(fs->d_depth, depth, depth_stride, drow, h, c->knobs.upload_blocks, cs) == hipSuccess) {}
     else if (depth_stride == drow) HIPCHECK(hipMemcpyAsync(fs->d_depth, depth, drow * h, hipMemcpyHostToDevice, cs));
     else HIPCHECK(hipMemcpy2DAsync(fs->d_depth, drow, depth, depth_stride, drow, h, hipMemcpyHostToDevice, cs));
     sec.lap(8);  // upload, depth
@@ -1152,16 +1166,8 @@ static int track_launch(revo_ctx* c, const revo_pyr* ref, const revo_pyr* curr, 
   // a single pair has the chip to itself: one more retry next to the candidate at the two finest levels costs its 16 workgroups
   // little and saves passes (sequential stream 4.23 -> 4.29 k frames/s, profiles/r06_single_stream_sweep.txt).  REVO_TRACK_KSPEC_ONE:
   // one digit per level (finest first) or one for all; an explicit REVO_TRACK_KSPEC applies to single pairs too.
-  {
-    static const std::string e1 = [] { const char* e = getenv("REVO_TRACK_KSPEC_ONE"); return std::string(e ? e : ""); }();
-    static const bool batch_set = [] { const char* e = getenv("REVO_TRACK_KSPEC"); return e && *e; }();
-    if (!e1.empty() || !batch_set)
-      for (int i = 0; i < REVO_L; ++i) {
-        int k = i < 2 ? 3 : TRACK_KMAX;
-        if (e1.size() == 1) k = e1[0] - '0'; else if (e1.size() > 1) k = e1[std::min<size_t>(i, e1.size() - 1)] - '0';
-        tp1.kspec[i] = std::max(1, std::min(TRACK_KMAX, k));
-      }
-  }
+  if (c->knobs.kspec_one_set)
+    for (int i = 0; i < REVO_L; ++i) tp1.kspec[i] = c->knobs.kspec_one[i];
   const unsigned seq = c->seq_next++;
   if (c->seq_next == 0) c->seq_next = 1;
   const int rc = chained_track_launch(c->device, c->knobs.track_depth, c->stream, [&](unsigned* d_resident) {
